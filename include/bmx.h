@@ -1,0 +1,146 @@
+/*
+ * bmx.h -- C ABI of libbmx.so: Boyer-Moore exact string matching on AMD
+ * Instinct MI355X (gfx950).  Plain pointers and sizes only; no C++ or torch
+ * types cross this boundary.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * reference checkout; the reference has no function API, its contract is the
+ * OpenCL kernel signature plus the host call sequence around it):
+ *
+ *   bmx_build_tables      BoyreMoore/BoyreMoore/BoyreMoore.cpp:150-190 (+ helpers :13-60)
+ *   bmx_ctx_create        BoyreMoore.cpp:217-231   clGetPlatformIDs .. clCreateCommandQueue
+ *   bmx_ctx_destroy       BoyreMoore.cpp:299-312   clRelease*
+ *   bmx_search            BoyreMoore.cpp:233-286   6x clCreateBuffer, 5x clEnqueueWriteBuffer,
+ *                                                  7x clSetKernelArg, clEnqueueNDRangeKernel,
+ *                                                  clEnqueueReadBuffer -- as ONE call that returns
+ *                                                  the match positions the kernel only printf()s
+ *                                                  (BoyreMoore/x64/Debug/kernel1.cl:24)
+ *   bmx_search_ranges     kernel1.cl:1 `search(A,B,se,ans,gstable,bstable,sublength)` with the
+ *                         launch of BoyreMoore.cpp:264-286: same seven arguments, same per-range
+ *                         counts in ans[]
+ *   bmx_search_device     the same scan on a text already resident in HBM (the reference re-uploads
+ *                         per iteration, BoyreMoore.cpp:246; its timer also starts after the upload, :258)
+ *
+ * Semantics (bit-exact with the reference kernel run as one work-item over
+ * [0, n-1]): match_positions receives, in ascending order, every
+ * start offset p with text[p .. p+m) == pattern, overlapping occurrences
+ * included (after a hit the reference advances by one, kernel1.cl:24).
+ *
+ * Domain: the reference is defined for 7-bit ASCII, 1 <= m <= 99, n < 2^31.
+ * libbmx accepts any byte values, 1 <= m <= BMX_MAX_PATTERN and 64-bit n; bytes
+ * >= 0x80 in the TEXT get the full shift m (they cannot occur in an ASCII
+ * pattern).  Patterns with bytes >= 0x80 are rejected by bmx_build_tables
+ * (BMX_ERR_DOMAIN) exactly where the reference would index bad[] out of range.
+ */
+#ifndef BMX_H
+#define BMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMX_MAX_PATTERN 512
+#define BMX_BAD_TABLE_SIZE 128 /* int badSymTab[128], BoyreMoore.cpp:151 */
+
+/* return codes */
+#define BMX_OK 0
+#define BMX_ERR_ARG (-1)      /* NULL pointer, m < 1, m > BMX_MAX_PATTERN, bad range          */
+#define BMX_ERR_DOMAIN (-2)   /* pattern byte >= 0x80                                          */
+#define BMX_ERR_TABLE (-3)    /* caller-supplied shift table holds a shift < 1                 */
+#define BMX_ERR_CAPACITY (-4) /* more matches than capacity: the first `capacity` ascending
+                                 offsets are returned, *n_matches holds the TRUE total          */
+#define BMX_ERR_HIP (-5)      /* a HIP runtime call failed; see bmx_last_error()               */
+#define BMX_ERR_NO_DEVICE (-6)
+
+typedef struct bmx_ctx bmx_ctx; /* one GPU: stream, device workspace, tables */
+
+/* ---- host-side table builder (pure C++, no GPU needed) ------------------- */
+
+/* bad[128]: m for every symbol, then m-1-i for pat[i], i = 0..m-2 (last write wins).
+ * good[m]: strong good-suffix shift indexed by the number of matched characters
+ * k = 1..m-1; good[0] is unused by the scan and set to 1. */
+int bmx_build_tables(const char *pat, int32_t m, int32_t bad[BMX_BAD_TABLE_SIZE], int32_t *good);
+
+/* ---- context -------------------------------------------------------------- */
+
+int bmx_device_count(void);
+int bmx_ctx_create(int device, bmx_ctx **out);
+void bmx_ctx_destroy(bmx_ctx *ctx);
+const char *bmx_last_error(void);
+const char *bmx_version(void);
+
+/* ---- the (text, pattern, match_positions) entry point --------------------- */
+
+/* Host buffers in, host buffers out.  Uploads the text, scans, sorts, downloads.
+ * ctx may be NULL (a context on device 0 is created and destroyed inside). */
+int bmx_search(bmx_ctx *ctx, const char *text, uint64_t n, const char *pat, int32_t m,
+               uint64_t *match_positions, uint64_t capacity, uint64_t *n_matches);
+
+/* Reference kernel contract: P inclusive ranges se[2P] (int, as the reference),
+ * ans[P] = hits whose whole window lies inside the range.  Tables are the
+ * caller's (as the reference passes its own); NULL tables are built inside. */
+int bmx_search_ranges(bmx_ctx *ctx, const char *text, uint64_t n, const char *pat,
+                      const int32_t *se, int32_t P, int32_t *ans, const int32_t *good,
+                      const int32_t *bad, int32_t m);
+
+/* ---- device-resident text -------------------------------------------------- */
+
+/* d_text: device pointer to n text bytes (any alignment).  d_match_positions:
+ * device buffer of `capacity` uint64.  Every reported offset is
+ * base_offset + (index into d_text): a shard of a larger corpus passes its
+ * global start.  Only windows that START in [0, n_own) are reported, while
+ * bytes up to n may be read: a shard passes n = n_own + (m-1) halo bytes
+ * (n_own == n - m + 1 or more means "all of it").
+ * `stream` is a hipStream_t (NULL = the context's own stream).  On return the
+ * offsets are sorted ascending in d_match_positions and *n_matches is valid
+ * (the call synchronises the stream once). */
+int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own,
+                      uint64_t base_offset, const char *pat, int32_t m, const int32_t *good,
+                      const int32_t *bad, uint64_t *d_match_positions, uint64_t capacity,
+                      uint64_t *n_matches, void *stream);
+
+/* Same, split in two so a caller can time / overlap / graph-capture the device
+ * work: _enqueue launches scan + ordering on `stream` and returns without
+ * synchronising; _finish synchronises, reads the count and orders the rare
+ * large result (> BMX_SMALL_SORT matches) with a radix sort. */
+int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own,
+                              uint64_t base_offset, const char *pat, int32_t m,
+                              const int32_t *good, const int32_t *bad,
+                              uint64_t *d_match_positions, uint64_t capacity, void *stream);
+int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t capacity,
+                             uint64_t *n_matches, void *stream);
+
+/* Text upload kept apart from the scan (repeated queries on a resident text). */
+int bmx_text_upload(bmx_ctx *ctx, const char *text, uint64_t n, void **d_text_out);
+int bmx_device_free(bmx_ctx *ctx, void *d_ptr);
+int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out);
+
+/* ---- measurement ----------------------------------------------------------- */
+
+/* Duration of the most recent scan kernel launched through ctx, from HIP events
+ * recorded on the launch stream around that kernel alone (ms); < 0 if none. */
+float bmx_last_scan_ms(bmx_ctx *ctx);
+/* Scan-kernel launch geometry actually used: out[0]=grid, out[1]=block,
+ * out[2]=tile bytes, out[3]=LDS bytes per workgroup. */
+int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[4]);
+/* Tuning knob for experiments: 0 = default kernel variant. */
+int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu);
+
+/* ---- synthetic corpus, generated in HBM ---------------------- */
+
+/* d_dst[j] = byte (start + j) of the counter-based splitmix64 stream;
+ * kind 0 = printable-95, kind 1 = ACGT. */
+int bmx_gen_text_device(bmx_ctx *ctx, void *d_dst, uint64_t start, uint64_t len, uint64_t seed,
+                        int kind, void *stream);
+/* Copy `pat` over [off, off+m) for every off in offsets[0..count) (GLOBAL stream
+ * offsets), clipped to the resident window [start, start+len).  Plants must not
+ * overlap each other within one call. */
+int bmx_plant_device(bmx_ctx *ctx, void *d_dst, uint64_t start, uint64_t len, const char *pat,
+                     int32_t m, const uint64_t *offsets, uint64_t count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMX_H */

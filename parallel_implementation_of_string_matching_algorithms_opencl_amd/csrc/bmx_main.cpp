@@ -1,0 +1,186 @@
+// bmx_main.cpp -- C++ host driver over libbmx.so.
+//
+// Keeps the I/O contract of the reference's console program
+// (BoyreMoore/BoyreMoore/BoyreMoore.cpp): a text file and a pattern file in
+// (defaults are the reference's hard-coded names, :77 and :82), the shift
+// tables built on the host (:150-190), the search repeated 10 times with the
+// text already on the device and the mean time printed (:211, :258, :288-292,
+// :314-315), per-range hit counts printed (:294-295).  What it does NOT keep:
+// the echo of the whole text (:92), the lossy 2-way split at spaces (:94-141)
+// as the default partition, and the per-iteration context/JIT (:217-256).
+//
+//   bmx_cli [--text F] [--pattern F] [--iters N] [--positions] [--max-print K]
+//           [--ranges P]      reference-compatible mode: split at spaces into P
+//                             inclusive ranges like BoyreMoore.cpp:94-141 and
+//                             print the per-range counts of bmx_search_ranges
+//           [--device D]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+#include <string>
+#include <vector>
+
+#include "bmx.h"
+
+namespace {
+
+bool read_file(const std::string &path, std::string &out)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return true;
+}
+
+// The reference's partition (BoyreMoore.cpp:94-141): words are maximal runs
+// between single spaces; P ranges of numberOfWords / P words each, inclusive
+// [start, end] with the separating space excluded; leftover words are dropped.
+std::vector<int32_t> split_like_reference(const std::string &text, int P)
+{
+    std::vector<int32_t> word_len;
+    int32_t cur = 0;
+    for (char ch : text) {
+        if (ch == ' ') {
+            word_len.push_back(cur);
+            cur = 0;
+        } else {
+            ++cur;
+        }
+    }
+    word_len.push_back(cur);
+    const size_t per = word_len.size() / (size_t)P;
+    std::vector<int32_t> se;
+    int64_t pos = 0;
+    size_t w = 0;
+    for (int r = 0; r < P; ++r) {
+        int64_t start = pos, end = pos;
+        for (size_t j = 0; j < per; ++j, ++w) end += word_len[w] + 1;
+        se.push_back((int32_t)start);
+        se.push_back((int32_t)(end - 2)); // last character of the last word
+        pos = end;
+    }
+    return se;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    std::string text_path = "inputEd.txt", pat_path = "input1Search.txt";
+    int iters = 10, device = 0, ranges = 0;
+    bool positions = false;
+    uint64_t max_print = 32;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto need = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) {
+                fprintf(stderr, "%s needs a value\n", name);
+                exit(2);
+            }
+            return argv[++i];
+        };
+        if (a == "--text") text_path = need("--text");
+        else if (a == "--pattern") pat_path = need("--pattern");
+        else if (a == "--iters") iters = atoi(need("--iters"));
+        else if (a == "--device") device = atoi(need("--device"));
+        else if (a == "--ranges") ranges = atoi(need("--ranges"));
+        else if (a == "--max-print") max_print = strtoull(need("--max-print"), nullptr, 10);
+        else if (a == "--positions") positions = true;
+        else {
+            fprintf(stderr, "unknown option %s\n", a.c_str());
+            return 2;
+        }
+    }
+
+    std::string text, pat;
+    if (!read_file(text_path, text)) {
+        fprintf(stderr, "cannot read text file %s\n", text_path.c_str());
+        return 1;
+    }
+    if (!read_file(pat_path, pat)) {
+        fprintf(stderr, "cannot read pattern file %s\n", pat_path.c_str());
+        return 1;
+    }
+    const uint64_t n = text.size();
+    const int32_t m = (int32_t)pat.size();
+    printf("text %s: %llu bytes, pattern %s: %d bytes\n", text_path.c_str(), (unsigned long long)n,
+           pat_path.c_str(), m);
+
+    int32_t bad[BMX_BAD_TABLE_SIZE];
+    std::vector<int32_t> good(m > 0 ? m : 1);
+    int rc = bmx_build_tables(pat.data(), m, bad, good.data());
+    if (rc != BMX_OK) {
+        fprintf(stderr, "bmx_build_tables failed: %d\n", rc);
+        return 1;
+    }
+
+    bmx_ctx *ctx = nullptr;
+    rc = bmx_ctx_create(device, &ctx);
+    if (rc != BMX_OK) {
+        fprintf(stderr, "bmx_ctx_create failed: %d (%s)\n", rc, bmx_last_error());
+        return 1;
+    }
+
+    if (ranges > 0) {
+        std::vector<int32_t> se = split_like_reference(text, ranges);
+        std::vector<int32_t> ans(ranges);
+        rc = bmx_search_ranges(ctx, text.data(), n, pat.data(), se.data(), ranges, ans.data(), good.data(), bad, m);
+        if (rc != BMX_OK) {
+            fprintf(stderr, "bmx_search_ranges failed: %d (%s)\n", rc, bmx_last_error());
+            return 1;
+        }
+        for (int r = 0; r < ranges; ++r)
+            printf("The no. of occurrences by process %d is %d   [range %d..%d]\n", r, ans[r], se[2 * r], se[2 * r + 1]);
+    }
+
+    // text resident once, searched `iters` times (the reference's timer also
+    // starts after the upload)
+    void *d_text = nullptr;
+    uint64_t *d_out = nullptr;
+    const uint64_t cap = n >= (uint64_t)m ? n - (uint64_t)m + 1 : 1;
+    rc = bmx_text_upload(ctx, text.data(), n, &d_text);
+    if (rc == BMX_OK) rc = bmx_device_alloc(ctx, cap * sizeof(uint64_t), (void **)&d_out);
+    if (rc != BMX_OK) {
+        fprintf(stderr, "device setup failed: %d (%s)\n", rc, bmx_last_error());
+        return 1;
+    }
+    double total = 0.0;
+    uint64_t n_matches = 0;
+    for (int it = 0; it < iters; ++it) {
+        auto t0 = std::chrono::steady_clock::now();
+        rc = bmx_search_device(ctx, d_text, n, n, 0, pat.data(), m, good.data(), bad, d_out, cap, &n_matches, nullptr);
+        auto t1 = std::chrono::steady_clock::now();
+        if (rc != BMX_OK) {
+            fprintf(stderr, "bmx_search_device failed: %d (%s)\n", rc, bmx_last_error());
+            return 1;
+        }
+        const double s = std::chrono::duration<double>(t1 - t0).count();
+        total += s;
+        printf("Time Spent: %.6f s (scan kernel %.3f ms)\n", s, bmx_last_scan_ms(ctx));
+    }
+    printf("occurrences: %llu\n", (unsigned long long)n_matches);
+    if (iters > 0) {
+        const double avg = total / iters;
+        printf("Average time = %.6f s  (%.3f GB/s)\n", avg, avg > 0 ? (double)n / avg / 1e9 : 0.0);
+    }
+
+    // the positions, through the host-buffer entry point (text, pattern, match_positions)
+    if (positions) {
+        std::vector<uint64_t> pos(n_matches ? n_matches : 1);
+        uint64_t got = 0;
+        rc = bmx_search(ctx, text.data(), n, pat.data(), m, pos.data(), pos.size(), &got);
+        if (rc != BMX_OK) {
+            fprintf(stderr, "bmx_search failed: %d (%s)\n", rc, bmx_last_error());
+            return 1;
+        }
+        for (uint64_t i = 0; i < got && i < max_print; ++i) printf("Found at : %llu\n", (unsigned long long)pos[i]);
+        if (got > max_print) printf("... %llu more\n", (unsigned long long)(got - max_print));
+    }
+    bmx_device_free(ctx, d_out);
+    bmx_device_free(ctx, d_text);
+    bmx_ctx_destroy(ctx);
+    return 0;
+}

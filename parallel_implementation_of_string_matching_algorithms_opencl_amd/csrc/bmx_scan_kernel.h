@@ -1,0 +1,188 @@
+// bmx_scan_kernel.h -- the Boyer-Moore scan kernel for gfx950 (CDNA4, wave64).
+//
+// Replaces the reference's OpenCL kernel `search`
+// (BoyreMoore/x64/Debug/kernel1.cl:1-36) launched by BoyreMoore.cpp:273-280
+// with global=2, local=1.  Same arithmetic per window (right-to-left compare,
+// bad-symbol shift on the window's LAST character minus k clamped to >= 1,
+// good-suffix shift indexed by k, maximum of the two, +1 after a hit), a
+// completely different schedule:
+//
+//   HBM --(global_load_lds_dwordx4, 16 B/lane, no VGPR round trip)--> LDS tile
+//   LDS tile --(one Boyer-Moore walker per lane over its own SEG-byte segment)--> hits
+//   hits --(wave __ballot / popcount ranks, one atomic per wave per event)--> HBM list
+//
+//  * A workgroup owns tiles t = blockIdx, blockIdx + grid, ...; tile t is the
+//    TILE = BLOCK*SEG window starts [t*TILE, (t+1)*TILE) and needs the bytes
+//    [t*TILE, (t+1)*TILE + m-1): the (m-1)-byte overlap lives only in LDS, HBM
+//    sees each text byte once plus the halo (<= 0.3 % at m = 99).
+//  * Two LDS buffers: the DMA for tile t+grid is issued before the walk over
+//    tile t and lands underneath it; one barrier per tile.
+//  * The shift tables and the pattern are broadcast into LDS once per workgroup.
+//  * SEG is 4*odd bytes, so walkers that advance in lockstep touch 32 different
+//    LDS banks (lane l reads bank (l*SEG/4 + i/4) % 32).
+//  * No MFMA anywhere: this is byte compare, bounded by HBM read bandwidth.
+//
+// Coordinates: "aligned coordinates" count bytes from text16, the caller's text
+// pointer rounded down to 16 B, so every DMA chunk is 16-B aligned whatever the
+// caller's alignment.  A chunk is only fetched if it overlaps a valid text byte,
+// hence no read ever touches a 16-B line the caller does not own a byte of.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bmx {
+
+constexpr int MAX_PATTERN = 512; // == BMX_MAX_PATTERN
+
+// Shift tables and pattern travel in the kernel-argument segment (1.8 KiB): no
+// device buffers to keep alive, no copies on the launch path, and every
+// workgroup broadcasts them into LDS from the scalar/constant cache.
+struct ScanTables {
+    uint16_t bad[128];          // shift for the window's last byte, already clamped to >= 1
+    uint16_t good[MAX_PATTERN]; // indexed by matched count k = 1..m-1
+    uint8_t pat[MAX_PATTERN];
+};
+
+struct ScanArgs {
+    const uint8_t *text16;   // caller's pointer rounded down to a multiple of 16
+    uint64_t first;          // aligned coordinate of text byte 0 (0..15)
+    uint64_t own_end;        // one past the last window START to report (aligned coords)
+    uint64_t data_end;       // one past the last valid text byte (aligned coords)
+    uint64_t out_bias;       // reported offset = aligned start + out_bias (mod 2^64)
+    uint64_t tile_begin;     // first tile index holding a window start
+    uint64_t tile_end;       // one past the last
+    uint64_t *out;           // match offsets, unordered append (NULL: count only)
+    uint64_t cap;            // capacity of out
+    unsigned long long *count; // TRUE number of matches (may exceed cap)
+    uint32_t m;
+    uint32_t halo16;         // (m-1) rounded up to a multiple of 16
+    ScanTables tab;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ lds_void *to_lds(const void *p)
+{
+    // the low 32 bits of a generic pointer into LDS are the LDS byte offset
+    return reinterpret_cast<lds_void *>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p)));
+}
+
+// One wave-instruction = 64 lanes x 16 B = 1 KiB from HBM straight into LDS.
+// `lds_wave_base` must be wave-uniform; lane L's 16 bytes land at base + 16*L.
+__device__ __forceinline__ void dma16(const uint8_t *gsrc_lane, const uint8_t *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((gbl_void *)gsrc_lane, to_lds(lds_wave_base), 16, 0, 0);
+}
+
+// Wave-aggregated append of one match per ACTIVE lane (called under divergence).
+__device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t pos)
+{
+    const uint64_t active = __ballot(1);
+    const uint32_t lane = __lane_id();
+    const int leader = __ffsll((unsigned long long)active) - 1;
+    const uint32_t rank = __popcll(active & ((1ull << lane) - 1ull));
+    unsigned long long base = 0;
+    if ((int)lane == leader) base = atomicAdd(a.count, (unsigned long long)__popcll(active));
+    base = __shfl(base, leader);
+    const uint64_t slot = base + rank;
+    if (a.out != nullptr && slot < a.cap) a.out[slot] = pos;
+}
+
+template <int BLOCK, int SEG>
+__global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
+{
+    static_assert(SEG % 4 == 0 && (SEG / 4) % 2 == 1, "SEG must be 4 * odd (LDS bank spread)");
+    static_assert(BLOCK % 64 == 0, "whole waves");
+    constexpr uint32_t TILE = BLOCK * SEG;
+    static_assert(TILE % 16 == 0, "tiles start on 16-B chunks");
+
+    const ScanArgs &a = a_in;
+    extern __shared__ uint4 smem_u4[];
+    uint8_t *smem = reinterpret_cast<uint8_t *>(smem_u4);
+    const uint32_t m = a.m;
+    const uint32_t buf_bytes = TILE + a.halo16; // multiple of 16
+    uint8_t *buf0 = smem;
+    uint8_t *buf1 = smem + buf_bytes;
+    uint16_t *s_bad = reinterpret_cast<uint16_t *>(smem + 2 * buf_bytes); // 256 x u16
+    uint16_t *s_good = s_bad + 256;                                        // m x u16
+    uint8_t *s_pat = reinterpret_cast<uint8_t *>(s_good + ((m + 7) & ~7u)); // m bytes
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lane = tid & 63;
+
+    // text bytes >= 0x80 cannot occur in an ASCII pattern: skip the whole window
+    for (uint32_t i = tid; i < 256; i += BLOCK) s_bad[i] = i < 128 ? a.tab.bad[i] : (uint16_t)m;
+    for (uint32_t i = tid; i < m; i += BLOCK) {
+        s_good[i] = a.tab.good[i];
+        s_pat[i] = a.tab.pat[i];
+    }
+
+    const uint32_t nchunk = buf_bytes >> 4; // 16-B chunks per tile incl. halo
+    auto issue_tile = [&](uint64_t t, uint8_t *dst) {
+        const uint64_t tile_off = t * (uint64_t)TILE;
+        const uint8_t *gsrc = a.text16 + tile_off;
+        // wave w takes chunks [64w, 64w+64), then strides by BLOCK
+        for (uint32_t c0 = wave * 64; c0 < nchunk; c0 += BLOCK) {
+            const uint32_t c = c0 + lane;
+            const uint64_t goff = tile_off + ((uint64_t)c << 4);
+            if (c < nchunk && goff < a.data_end) dma16(gsrc + ((uint64_t)c << 4), dst + ((uint64_t)c0 << 4));
+        }
+    };
+
+    uint64_t t = a.tile_begin + blockIdx.x;
+    if (t < a.tile_end) issue_tile(t, buf0);
+    uint32_t cur = 0;
+
+    for (; t < a.tile_end; t += gridDim.x) {
+        // (A) this tile's DMA has landed for every wave, and every wave has
+        //     finished walking the other buffer, which is refilled next.
+        __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
+        __syncthreads();
+
+        const uint64_t tn = t + gridDim.x;
+        if (tn < a.tile_end) issue_tile(tn, cur ? buf0 : buf1);
+
+        const uint8_t *T = cur ? buf1 : buf0;
+        const uint64_t tile_off = t * (uint64_t)TILE;
+
+        // this lane's window starts, tile-local: [lo, hi)
+        uint32_t lo = tid * SEG;
+        uint32_t hi = lo + SEG;
+        if (tile_off < a.first) {
+            const uint32_t f = (uint32_t)(a.first - tile_off);
+            lo = lo > f ? lo : f;
+        }
+        const uint64_t rem = a.own_end - tile_off; // > 0 because t < tile_end
+        if (rem < (uint64_t)hi) hi = (uint32_t)rem;
+
+        if (lo < hi) {
+            const uint32_t plast = s_pat[m - 1];
+            uint32_t i = lo + m - 1;          // index of the window's last character
+            const uint32_t ilim = hi + m - 1; // exclusive
+            while (i < ilim) {
+                const uint32_t c = T[i];
+                const uint32_t b = s_bad[c];
+                if (c != plast) { // k == 0: shift = max(bad[c] - 0, 1), kernel1.cl:28,30
+                    i += b;
+                    continue;
+                }
+                uint32_t k = 1; // kernel1.cl:20-22
+                while (k < m && T[i - k] == s_pat[m - 1 - k]) ++k;
+                if (k == m) { // kernel1.cl:24
+                    emit_hit(a, tile_off + (uint64_t)(i - (m - 1)) + a.out_bias);
+                    i += 1;
+                    continue;
+                }
+                const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28
+                const int d2 = (int)s_good[k];                              // kernel1.cl:29
+                i += (uint32_t)(d1 > d2 ? d1 : d2);                         // kernel1.cl:31
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+} // namespace bmx

@@ -1,0 +1,453 @@
+// bmx_shim.hip -- the C ABI of libbmx.so (include/bmx.h): a thin HIP shim that
+// stands where the reference's OpenCL host plumbing stood
+// (BoyreMoore/BoyreMoore/BoyreMoore.cpp:213-312: context, six buffers, five
+// blocking writes, runtime JIT, seven kernel arguments, NDRange, blocking read).
+// No JIT (the kernel is compiled for gfx950 ahead of time), no per-call context,
+// the text can stay resident, and match positions come back as an ordered list
+// instead of device printf lines.
+#include "bmx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "bmx_aux_kernels.h"
+#include "bmx_scan_kernel.h"
+
+static_assert(bmx::MAX_PATTERN == BMX_MAX_PATTERN, "header and kernel disagree");
+
+// bmx_sort.hip
+int bmx_internal_radix_sort(uint64_t *d_keys, uint64_t n, hipStream_t stream, char *err, size_t errlen);
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return BMX_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+// Scan-kernel variants: (threads per workgroup, bytes of window starts per lane).
+struct Variant {
+    int block;
+    int seg;
+    void (*kernel)(const bmx::ScanArgs);
+};
+
+#define BMX_VARIANT(B, S) {B, S, bmx::scan_kernel<B, S>}
+const Variant g_variants[] = {
+    BMX_VARIANT(256, 132), // 0: default
+    BMX_VARIANT(256, 68),  // 1
+    BMX_VARIANT(512, 68),  // 2
+    BMX_VARIANT(256, 260), // 3
+    BMX_VARIANT(512, 132), // 4
+    BMX_VARIANT(1024, 68), // 5
+    BMX_VARIANT(256, 36),  // 6
+    BMX_VARIANT(512, 36),  // 7
+};
+constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
+constexpr uint32_t LDS_PER_CU = 160 * 1024;
+
+} // namespace
+
+struct bmx_ctx {
+    int device = 0;
+    int num_cu = 256;
+    int variant = 0;
+    int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
+    unsigned long long *d_count = nullptr;
+    unsigned long long *h_count = nullptr; // pinned
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int lds_attr_set[N_VARIANTS] = {};
+};
+
+namespace {
+
+uint32_t lds_bytes_for(const Variant &v, int32_t m)
+{
+    const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
+    const uint32_t buf = (uint32_t)v.block * v.seg + halo16;
+    const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u);
+    return 2 * buf + tables;
+}
+
+int blocks_per_cu_for(const bmx_ctx *ctx, const Variant &v, int32_t m)
+{
+    int by_lds = (int)(LDS_PER_CU / lds_bytes_for(v, m));
+    int by_waves = 2048 / v.block;
+    int b = std::max(1, std::min(by_lds, by_waves));
+    if (ctx->blocks_per_cu > 0) b = std::min(b, ctx->blocks_per_cu);
+    return b;
+}
+
+// Convert the caller's int32 tables (or build them) into the kernel-argument layout.
+int fill_tables(bmx::ScanTables &tab, const char *pat, int32_t m, const int32_t *good, const int32_t *bad)
+{
+    std::vector<int32_t> own_good;
+    int32_t own_bad[BMX_BAD_TABLE_SIZE];
+    if (!good || !bad) {
+        own_good.resize(m);
+        int rc = bmx_build_tables(pat, m, own_bad, own_good.data());
+        if (rc != BMX_OK) return rc;
+        good = own_good.data();
+        bad = own_bad;
+    }
+    // kernel1.cl:28 clamps (bad - k) to >= 1, and k == 0 uses bad as is
+    for (int c = 0; c < BMX_BAD_TABLE_SIZE; ++c) tab.bad[c] = (uint16_t)std::min(std::max(bad[c], 1), 65535);
+    for (int k = 0; k < m; ++k) tab.good[k] = (uint16_t)std::min(std::max(good[k], 0), 65535);
+    std::memcpy(tab.pat, pat, (size_t)m);
+    return BMX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *bmx_last_error(void) { return g_err; }
+const char *bmx_version(void) { return "bmx 0.1 (gfx950)"; }
+
+int bmx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bmx_ctx_create(int device, bmx_ctx **out)
+{
+    if (!out) return BMX_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        set_err("no HIP device %d (count %d)", device, n);
+        return BMX_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+    bmx_ctx *ctx = new bmx_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->num_cu = prop.multiProcessorCount;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_count, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_count, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e != hipSuccess) {
+        set_err("bmx_ctx_create: %s", hipGetErrorString(e));
+        bmx_ctx_destroy(ctx);
+        return BMX_ERR_HIP;
+    }
+    *out = ctx;
+    return BMX_OK;
+}
+
+void bmx_ctx_destroy(bmx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_count) (void)hipFree(ctx->d_count);
+    if (ctx->h_count) (void)hipHostFree(ctx->h_count);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu)
+{
+    if (!ctx || variant < 0 || variant >= N_VARIANTS || blocks_per_cu < 0) return BMX_ERR_ARG;
+    ctx->variant = variant;
+    ctx->blocks_per_cu = blocks_per_cu;
+    return BMX_OK;
+}
+
+int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[4])
+{
+    if (!ctx || !out || m < 1 || m > BMX_MAX_PATTERN) return BMX_ERR_ARG;
+    const Variant &v = g_variants[ctx->variant];
+    out[0] = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
+    out[1] = v.block;
+    out[2] = (uint64_t)v.block * v.seg;
+    out[3] = lds_bytes_for(v, m);
+    return BMX_OK;
+}
+
+float bmx_last_scan_ms(bmx_ctx *ctx)
+{
+    if (!ctx || !ctx->timed) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own,
+                              uint64_t base_offset, const char *pat, int32_t m, const int32_t *good,
+                              const int32_t *bad, uint64_t *d_match_positions, uint64_t capacity,
+                              void *stream_v)
+{
+    if (!ctx || !pat || m < 1 || m > BMX_MAX_PATTERN) return BMX_ERR_ARG;
+    if (capacity > 0 && !d_match_positions) return BMX_ERR_ARG;
+    if (n > 0 && !d_text) return BMX_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned long long), stream));
+    ctx->timed = false;
+
+    // windows that fit: starts 0 .. n-m; of those the caller owns [0, n_own)
+    if (n < (uint64_t)m) return BMX_OK;
+    const uint64_t n_starts = std::min<uint64_t>(n - (uint64_t)m + 1, n_own);
+    if (n_starts == 0) return BMX_OK;
+
+    const Variant &v = g_variants[ctx->variant];
+    const uint64_t tile = (uint64_t)v.block * v.seg;
+    const uintptr_t addr = (uintptr_t)d_text;
+    const uint64_t mis = addr & 15u;
+
+    bmx::ScanArgs a;
+    int rc = fill_tables(a.tab, pat, m, good, bad);
+    if (rc != BMX_OK) return rc;
+    a.text16 = (const uint8_t *)(addr - mis);
+    a.first = mis;
+    a.own_end = mis + n_starts;
+    a.data_end = mis + n;
+    a.out_bias = base_offset - mis;
+    a.tile_begin = 0; // mis < 16 <= tile
+    a.tile_end = (a.own_end + tile - 1) / tile;
+    a.out = capacity ? d_match_positions : nullptr;
+    a.cap = capacity;
+    a.count = ctx->d_count;
+    a.m = (uint32_t)m;
+    a.halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
+
+    const uint32_t lds = lds_bytes_for(v, m);
+    if (lds > LDS_PER_CU) {
+        set_err("LDS need %u exceeds %u", lds, LDS_PER_CU);
+        return BMX_ERR_ARG;
+    }
+    if (ctx->lds_attr_set[ctx->variant] < (int)lds) {
+        HIPCHK(hipFuncSetAttribute((const void *)v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->lds_attr_set[ctx->variant] = (int)lds;
+    }
+    const uint64_t ntiles = a.tile_end - a.tile_begin;
+    const uint64_t max_grid = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, max_grid);
+
+    HIPCHK(hipEventRecord(ctx->ev0, stream));
+    hipLaunchKernelGGL(v.kernel, dim3(grid), dim3(v.block), lds, stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev1, stream));
+    ctx->timed = true;
+
+    if (capacity > 1) {
+        hipLaunchKernelGGL(bmx::small_sort_kernel, dim3(1), dim3(bmx::SMALL_SORT_THREADS),
+                           bmx::SMALL_SORT_MAX * sizeof(uint64_t), stream, d_match_positions, ctx->d_count,
+                           capacity);
+        HIPCHK(hipGetLastError());
+    }
+    return BMX_OK;
+}
+
+int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t capacity,
+                             uint64_t *n_matches, void *stream_v)
+{
+    if (!ctx) return BMX_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(ctx->h_count, ctx->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    const uint64_t total = *ctx->h_count;
+    if (n_matches) *n_matches = total;
+    const uint64_t stored = std::min(total, capacity);
+    if (stored > (uint64_t)bmx::SMALL_SORT_MAX) {
+        int rc = bmx_internal_radix_sort(d_match_positions, stored, stream, g_err, sizeof g_err);
+        if (rc != BMX_OK) return rc;
+    }
+    return total > capacity && capacity > 0 ? BMX_ERR_CAPACITY : BMX_OK;
+}
+
+int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own, uint64_t base_offset,
+                      const char *pat, int32_t m, const int32_t *good, const int32_t *bad,
+                      uint64_t *d_match_positions, uint64_t capacity, uint64_t *n_matches, void *stream)
+{
+    int rc = bmx_search_device_enqueue(ctx, d_text, n, n_own, base_offset, pat, m, good, bad,
+                                       d_match_positions, capacity, stream);
+    if (rc != BMX_OK) return rc;
+    return bmx_search_device_finish(ctx, d_match_positions, capacity, n_matches, stream);
+}
+
+int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out)
+{
+    if (!ctx || !d_ptr_out) return BMX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMalloc(d_ptr_out, bytes ? bytes : 1));
+    return BMX_OK;
+}
+
+int bmx_device_free(bmx_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return BMX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (d_ptr) HIPCHK(hipFree(d_ptr));
+    return BMX_OK;
+}
+
+int bmx_text_upload(bmx_ctx *ctx, const char *text, uint64_t n, void **d_text_out)
+{
+    if (!ctx || !d_text_out || (n > 0 && !text)) return BMX_ERR_ARG;
+    int rc = bmx_device_alloc(ctx, n, d_text_out);
+    if (rc != BMX_OK) return rc;
+    if (n) HIPCHK(hipMemcpy(*d_text_out, text, n, hipMemcpyHostToDevice));
+    return BMX_OK;
+}
+
+int bmx_search(bmx_ctx *ctx_in, const char *text, uint64_t n, const char *pat, int32_t m,
+               uint64_t *match_positions, uint64_t capacity, uint64_t *n_matches)
+{
+    if (!pat || m < 1 || m > BMX_MAX_PATTERN || (n > 0 && !text)) return BMX_ERR_ARG;
+    if (capacity > 0 && !match_positions) return BMX_ERR_ARG;
+    if (n_matches) *n_matches = 0;
+    // table errors (pattern outside the ASCII domain) before any device work
+    {
+        int32_t bad[BMX_BAD_TABLE_SIZE];
+        std::vector<int32_t> good(m);
+        int rc = bmx_build_tables(pat, m, bad, good.data());
+        if (rc != BMX_OK) return rc;
+    }
+    if (n < (uint64_t)m) return BMX_OK;
+
+    bmx_ctx *ctx = ctx_in;
+    if (!ctx) {
+        int rc = bmx_ctx_create(0, &ctx);
+        if (rc != BMX_OK) return rc;
+    }
+    void *d_text = nullptr;
+    uint64_t *d_out = nullptr;
+    const uint64_t dev_cap = std::min<uint64_t>(capacity, n - (uint64_t)m + 1);
+    uint64_t total = 0;
+    int rc = bmx_text_upload(ctx, text, n, &d_text);
+    if (rc == BMX_OK && dev_cap) rc = bmx_device_alloc(ctx, dev_cap * sizeof(uint64_t), (void **)&d_out);
+    if (rc == BMX_OK)
+        rc = bmx_search_device(ctx, d_text, n, n, 0, pat, m, nullptr, nullptr, d_out, dev_cap, &total, nullptr);
+    if (rc == BMX_OK || rc == BMX_ERR_CAPACITY) {
+        const uint64_t stored = std::min(total, dev_cap);
+        if (stored) {
+            hipError_t e = hipMemcpy(match_positions, d_out, stored * sizeof(uint64_t), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                set_err("download of matches: %s", hipGetErrorString(e));
+                rc = BMX_ERR_HIP;
+            }
+        }
+        if (n_matches) *n_matches = total;
+        if (rc == BMX_OK && total > capacity) rc = BMX_ERR_CAPACITY;
+    }
+    if (d_out) (void)hipFree(d_out);
+    if (d_text) (void)hipFree(d_text);
+    if (!ctx_in) bmx_ctx_destroy(ctx);
+    return rc;
+}
+
+int bmx_search_ranges(bmx_ctx *ctx_in, const char *text, uint64_t n, const char *pat, const int32_t *se,
+                      int32_t P, int32_t *ans, const int32_t *good, const int32_t *bad, int32_t m)
+{
+    if (!text || !pat || !se || !ans || P < 0 || m < 1 || m > BMX_MAX_PATTERN) return BMX_ERR_ARG;
+    if ((good == nullptr) != (bad == nullptr)) return BMX_ERR_ARG;
+    for (int r = 0; r < P; ++r) {
+        ans[r] = 0;
+        const int64_t s = se[2 * r], e = se[2 * r + 1];
+        if (s < 0 || (e >= s && (uint64_t)e >= n)) return BMX_ERR_ARG;
+    }
+    if (!good) {
+        int32_t tb[BMX_BAD_TABLE_SIZE];
+        std::vector<int32_t> tg(m);
+        int rc = bmx_build_tables(pat, m, tb, tg.data());
+        if (rc != BMX_OK) return rc;
+    }
+    bmx_ctx *ctx = ctx_in;
+    if (!ctx) {
+        int rc = bmx_ctx_create(0, &ctx);
+        if (rc != BMX_OK) return rc;
+    }
+    void *d_text = nullptr;
+    int rc = bmx_text_upload(ctx, text, n, &d_text);
+    for (int r = 0; r < P && rc == BMX_OK; ++r) {
+        const int64_t s = se[2 * r], e = se[2 * r + 1];
+        if (e < s) continue;
+        // inclusive range [s, e] as in kernel1.cl:14-19: windows wholly inside it
+        const uint64_t len = (uint64_t)(e - s) + 1;
+        uint64_t total = 0;
+        rc = bmx_search_device(ctx, (const char *)d_text + s, len, len, (uint64_t)s, pat, m, good, bad, nullptr,
+                               0, &total, nullptr);
+        ans[r] = (int32_t)total;
+    }
+    if (d_text) (void)hipFree(d_text);
+    if (!ctx_in) bmx_ctx_destroy(ctx);
+    return rc;
+}
+
+int bmx_gen_text_device(bmx_ctx *ctx, void *d_dst, uint64_t start, uint64_t len, uint64_t seed, int kind,
+                        void *stream_v)
+{
+    if (!ctx || (len > 0 && !d_dst) || (kind != 0 && kind != 1)) return BMX_ERR_ARG;
+    if (len == 0) return BMX_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t nwords = ((start + len + 7) >> 3) - (start >> 3);
+    const uint32_t block = 256;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((nwords + block - 1) / block, (uint64_t)ctx->num_cu * 32);
+    hipLaunchKernelGGL(bmx::gen_text_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream_v, (uint8_t *)d_dst,
+                       start, len, seed, kind);
+    HIPCHK(hipGetLastError());
+    return BMX_OK;
+}
+
+int bmx_plant_device(bmx_ctx *ctx, void *d_dst, uint64_t start, uint64_t len, const char *pat, int32_t m,
+                     const uint64_t *offsets, uint64_t count, void *stream_v)
+{
+    if (!ctx || !pat || m < 1 || m > BMX_MAX_PATTERN || (count > 0 && !offsets) || (len > 0 && !d_dst))
+        return BMX_ERR_ARG;
+    if (count == 0 || len == 0) return BMX_OK;
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIPCHK(hipSetDevice(ctx->device));
+    uint64_t *d_off = nullptr;
+    uint8_t *d_pat = nullptr;
+    HIPCHK(hipMalloc(&d_off, count * sizeof(uint64_t)));
+    hipError_t e = hipMalloc(&d_pat, (size_t)m);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, offsets, count * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pat, pat, (size_t)m, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) {
+        const uint64_t total = count * (uint64_t)m;
+        const uint32_t block = 256;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((total + block - 1) / block, (uint64_t)ctx->num_cu * 8);
+        hipLaunchKernelGGL(bmx::plant_kernel, dim3(grid), dim3(block), 0, stream, (uint8_t *)d_dst, start, len,
+                           d_pat, (uint32_t)m, d_off, count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_off);
+    if (d_pat) (void)hipFree(d_pat);
+    if (e != hipSuccess) {
+        set_err("bmx_plant_device: %s", hipGetErrorString(e));
+        return BMX_ERR_HIP;
+    }
+    return BMX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,294 @@
+"""ctypes binding of libbmx.so (include/bmx.h) -- the Python face of the C ABI.
+
+The reference (BoyreMoore/BoyreMoore/BoyreMoore.cpp) has no callable API: its
+contract is "text + pattern in, match positions (device printf) and per-range
+counts out".  This module keeps that contract and nothing else:
+
+* :func:`build_tables`  -- BoyreMoore.cpp:150-190 (host shift tables)
+* :func:`search`        -- (text, pattern) -> ascending match positions, host buffers
+* :func:`search_ranges` -- the kernel's own signature, kernel1.cl:1: ranges ``se`` in,
+  per-range counts ``ans`` out
+* :class:`Context`      -- one GPU; ``search_device`` works on a text resident in HBM
+  (a ``torch`` uint8 CUDA tensor or a raw device pointer)
+
+There is NO CPU fallback: if libbmx.so is missing or no GPU is present every
+device entry point raises.  torch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbmx.so")
+
+MAX_PATTERN = 512
+BAD_TABLE_SIZE = 128
+
+OK = 0
+ERR_ARG, ERR_DOMAIN, ERR_TABLE, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
+_ERR_NAMES = {
+    ERR_ARG: "BMX_ERR_ARG", ERR_DOMAIN: "BMX_ERR_DOMAIN", ERR_TABLE: "BMX_ERR_TABLE",
+    ERR_CAPACITY: "BMX_ERR_CAPACITY", ERR_HIP: "BMX_ERR_HIP", ERR_NO_DEVICE: "BMX_ERR_NO_DEVICE",
+}
+
+_i32p = C.POINTER(C.c_int32)
+_u64p = C.POINTER(C.c_uint64)
+
+# every symbol include/bmx.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("bmx_build_tables", C.c_int, [C.c_char_p, C.c_int32, _i32p, _i32p]),
+    ("bmx_device_count", C.c_int, []),
+    ("bmx_ctx_create", C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    ("bmx_ctx_destroy", None, [C.c_void_p]),
+    ("bmx_last_error", C.c_char_p, []),
+    ("bmx_version", C.c_char_p, []),
+    ("bmx_search", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int32, _u64p, C.c_uint64, _u64p]),
+    ("bmx_search_ranges", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, _i32p, C.c_int32, _i32p,
+                                    _i32p, _i32p, C.c_int32]),
+    ("bmx_search_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p,
+                                    C.c_int32, _i32p, _i32p, C.c_void_p, C.c_uint64, _u64p, C.c_void_p]),
+    ("bmx_search_device_enqueue", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p,
+                                            C.c_int32, _i32p, _i32p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    ("bmx_search_device_finish", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, _u64p, C.c_void_p]),
+    ("bmx_text_upload", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    ("bmx_device_free", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("bmx_device_alloc", C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    ("bmx_last_scan_ms", C.c_float, [C.c_void_p]),
+    ("bmx_scan_geometry", C.c_int, [C.c_void_p, C.c_int32, _u64p]),
+    ("bmx_set_variant", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("bmx_gen_text_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]),
+    ("bmx_plant_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int32, _u64p,
+                                   C.c_uint64, C.c_void_p]),
+]
+
+
+class BmxError(RuntimeError):
+    def __init__(self, rc: int, what: str, detail: str = ""):
+        self.rc = rc
+        super().__init__(f"{what}: {_ERR_NAMES.get(rc, rc)}" + (f" ({detail})" if detail else ""))
+
+
+_lib = None
+
+
+def lib():
+    """Load libbmx.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C parallel_implementation_of_string_matching_algorithms_opencl_amd/csrc`")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str, allow=()):
+    if rc != OK and rc not in allow:
+        raise BmxError(rc, what, lib().bmx_last_error().decode(errors="replace"))
+    return rc
+
+
+def _pat_bytes(pattern) -> bytes:
+    if isinstance(pattern, str):
+        pattern = pattern.encode("latin-1")
+    pattern = bytes(pattern)
+    return pattern
+
+
+def _host_text(text) -> Tuple[C.c_void_p, int, object]:
+    if isinstance(text, str):
+        text = text.encode("latin-1")
+    if isinstance(text, (bytes, bytearray)):
+        b = bytes(text)
+        return C.cast(C.c_char_p(b), C.c_void_p), len(b), b
+    arr = np.ascontiguousarray(text, dtype=np.uint8)
+    return C.c_void_p(arr.ctypes.data), arr.size, arr
+
+
+def build_tables(pattern) -> Tuple[np.ndarray, np.ndarray]:
+    """(bad[128], good[m]) int32, identical to the reference's host tables."""
+    pat = _pat_bytes(pattern)
+    m = len(pat)
+    bad = np.zeros(BAD_TABLE_SIZE, dtype=np.int32)
+    good = np.zeros(max(m, 1), dtype=np.int32)
+    _check(lib().bmx_build_tables(pat, m, bad.ctypes.data_as(_i32p), good.ctypes.data_as(_i32p)), "bmx_build_tables")
+    return bad, good[:m]
+
+
+class Context:
+    """One GPU.  Mirrors the reference's per-iteration context/queue
+    (BoyreMoore.cpp:217-231) but is created once and reused."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().bmx_ctx_create(device, C.byref(self._h)), "bmx_ctx_create")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().bmx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- host buffers ------------------------------------------------------
+    def search(self, text, pattern, capacity: Optional[int] = None) -> np.ndarray:
+        """Ascending start offsets of every occurrence of pattern in text."""
+        pat = _pat_bytes(pattern)
+        tptr, n, keep = _host_text(text)
+        m = len(pat)
+        cap = capacity if capacity is not None else max(1, min(max(n - m + 1, 1), 1 << 20))
+        while True:
+            out = np.empty(max(cap, 1), dtype=np.uint64)
+            total = C.c_uint64(0)
+            rc = lib().bmx_search(self._h, tptr, n, pat, m, out.ctypes.data_as(_u64p), cap, C.byref(total))
+            if rc == ERR_CAPACITY and capacity is None:
+                cap = int(total.value)
+                continue
+            _check(rc, "bmx_search")
+            del keep
+            return out[: int(total.value)].copy()
+
+    def search_ranges(self, text, pattern, ranges, tables=None) -> np.ndarray:
+        """Reference kernel contract: counts per inclusive range [se[2r], se[2r+1]]."""
+        pat = _pat_bytes(pattern)
+        tptr, n, keep = _host_text(text)
+        se = np.ascontiguousarray(ranges, dtype=np.int32).reshape(-1)
+        P = se.size // 2
+        ans = np.zeros(max(P, 1), dtype=np.int32)
+        gp = bp = None
+        if tables is not None:
+            bad, good = tables
+            bad = np.ascontiguousarray(bad, dtype=np.int32)
+            good = np.ascontiguousarray(good, dtype=np.int32)
+            gp, bp = good.ctypes.data_as(_i32p), bad.ctypes.data_as(_i32p)
+        _check(lib().bmx_search_ranges(self._h, tptr, n, pat, se.ctypes.data_as(_i32p), P,
+                                       ans.ctypes.data_as(_i32p), gp, bp, len(pat)), "bmx_search_ranges")
+        return ans[:P].copy()
+
+    # -- device-resident text ---------------------------------------------
+    def search_device(self, d_text, pattern, *, n: Optional[int] = None, n_own: Optional[int] = None,
+                      base_offset: int = 0, out=None, capacity: Optional[int] = None, tables=None):
+        """Scan a text resident in HBM.  ``d_text``/``out`` are torch CUDA tensors
+        (uint8 / int64-or-uint64 storage).  Returns (positions tensor view, total)."""
+        import torch
+
+        pat = _pat_bytes(pattern)
+        m = len(pat)
+        if n is None:
+            n = d_text.numel()
+        if n_own is None:
+            n_own = n
+        if out is None:
+            cap = capacity if capacity is not None else 1 << 16
+            out = torch.empty(max(cap, 1), dtype=torch.int64, device=d_text.device)
+        cap = out.numel() if capacity is None else min(capacity, out.numel())
+        gp = bp = None
+        if tables is not None:
+            bad, good = tables
+            bad = np.ascontiguousarray(bad, dtype=np.int32)
+            good = np.ascontiguousarray(good, dtype=np.int32)
+            gp, bp = good.ctypes.data_as(_i32p), bad.ctypes.data_as(_i32p)
+        stream = C.c_void_p(torch.cuda.current_stream(d_text.device).cuda_stream)
+        total = C.c_uint64(0)
+        rc = lib().bmx_search_device(self._h, C.c_void_p(d_text.data_ptr()), n, n_own, base_offset, pat, m, gp, bp,
+                                     C.c_void_p(out.data_ptr()), cap, C.byref(total), stream)
+        _check(rc, "bmx_search_device", allow=(ERR_CAPACITY,))
+        return out[: min(int(total.value), cap)], int(total.value)
+
+    def enqueue(self, d_text, pattern, out, *, n=None, n_own=None, base_offset=0, tables=None):
+        """Launch scan + ordering on torch's current stream; no synchronisation."""
+        import torch
+
+        pat = _pat_bytes(pattern)
+        if n is None:
+            n = d_text.numel()
+        if n_own is None:
+            n_own = n
+        gp = bp = None
+        if tables is not None:
+            bad, good = tables
+            self._keep = (np.ascontiguousarray(bad, dtype=np.int32), np.ascontiguousarray(good, dtype=np.int32))
+            bp, gp = self._keep[0].ctypes.data_as(_i32p), self._keep[1].ctypes.data_as(_i32p)
+        stream = C.c_void_p(torch.cuda.current_stream(d_text.device).cuda_stream)
+        _check(lib().bmx_search_device_enqueue(self._h, C.c_void_p(d_text.data_ptr()), n, n_own, base_offset, pat,
+                                               len(pat), gp, bp, C.c_void_p(out.data_ptr()), out.numel(), stream),
+               "bmx_search_device_enqueue")
+
+    def finish(self, out) -> int:
+        import torch
+
+        stream = C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
+        total = C.c_uint64(0)
+        rc = lib().bmx_search_device_finish(self._h, C.c_void_p(out.data_ptr()), out.numel(), C.byref(total), stream)
+        _check(rc, "bmx_search_device_finish", allow=(ERR_CAPACITY,))
+        return int(total.value)
+
+    def last_scan_ms(self) -> float:
+        return float(lib().bmx_last_scan_ms(self._h))
+
+    def geometry(self, m: int) -> dict:
+        g = (C.c_uint64 * 4)()
+        _check(lib().bmx_scan_geometry(self._h, m, g), "bmx_scan_geometry")
+        return {"grid": int(g[0]), "block": int(g[1]), "tile_bytes": int(g[2]), "lds_bytes": int(g[3])}
+
+    def set_variant(self, variant: int, blocks_per_cu: int = 0):
+        _check(lib().bmx_set_variant(self._h, variant, blocks_per_cu), "bmx_set_variant")
+
+    # -- synthetic corpus in HBM ------------------------------------------
+    def gen_text(self, d_dst, start: int, seed: int, kind: int = 0, length: Optional[int] = None):
+        import torch
+
+        length = d_dst.numel() if length is None else length
+        stream = C.c_void_p(torch.cuda.current_stream(d_dst.device).cuda_stream)
+        _check(lib().bmx_gen_text_device(self._h, C.c_void_p(d_dst.data_ptr()), start, length,
+                                         seed & (2**64 - 1), kind, stream), "bmx_gen_text_device")
+
+    def plant(self, d_dst, start: int, pattern, offsets, length: Optional[int] = None):
+        import torch
+
+        pat = _pat_bytes(pattern)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        length = d_dst.numel() if length is None else length
+        stream = C.c_void_p(torch.cuda.current_stream(d_dst.device).cuda_stream)
+        _check(lib().bmx_plant_device(self._h, C.c_void_p(d_dst.data_ptr()), start, length, pat, len(pat),
+                                      off.ctypes.data_as(_u64p), off.size, stream), "bmx_plant_device")
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def search(text, pattern) -> np.ndarray:
+    """(text, pattern) -> match_positions, the north-star entry point."""
+    return default_context().search(text, pattern)
+
+
+def search_ranges(text, pattern, ranges, tables=None) -> np.ndarray:
+    return default_context().search_ranges(text, pattern, ranges, tables)
