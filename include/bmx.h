@@ -48,9 +48,11 @@ extern "C" {
 #define BMX_OK 0
 #define BMX_ERR_ARG (-1)      /* NULL pointer, m < 1, m > BMX_MAX_PATTERN, bad range          */
 #define BMX_ERR_DOMAIN (-2)   /* pattern byte >= 0x80                                          */
-#define BMX_ERR_TABLE (-3)    /* caller-supplied shift table holds a shift < 1                 */
-#define BMX_ERR_CAPACITY (-4) /* more matches than capacity: the first `capacity` ascending
-                                 offsets are returned, *n_matches holds the TRUE total          */
+#define BMX_ERR_TABLE (-3)    /* reserved (shift tables cannot stall the scan: shifts are clamped
+                                 to >= 1 exactly as kernel1.cl:28 clamps d1)                   */
+#define BMX_ERR_CAPACITY (-4) /* more matches than capacity: `capacity` of them are returned
+                                 (which ones is unspecified), ascending; *n_matches holds the
+                                 TRUE total so the caller can retry with room for all        */
 #define BMX_ERR_HIP (-5)      /* a HIP runtime call failed; see bmx_last_error()               */
 #define BMX_ERR_NO_DEVICE (-6)
 
@@ -93,7 +95,7 @@ int bmx_search_ranges(bmx_ctx *ctx, const char *text, uint64_t n, const char *pa
  * global start.  Only windows that START in [0, n_own) are reported, while
  * bytes up to n may be read: a shard passes n = n_own + (m-1) halo bytes
  * (n_own == n - m + 1 or more means "all of it").
- * `stream` is a hipStream_t (NULL = the context's own stream).  On return the
+ * `stream` is a hipStream_t used as is (NULL = the null stream).  On return the
  * offsets are sorted ascending in d_match_positions and *n_matches is valid
  * (the call synchronises the stream once). */
 int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own,
@@ -111,6 +113,22 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
                               uint64_t *d_match_positions, uint64_t capacity, void *stream);
 int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t capacity,
                              uint64_t *n_matches, void *stream);
+
+/* ---- multi-GPU exchange helpers (the collective itself is RCCL, outside) ------ */
+
+/* Copy the match count of the most recent enqueue on ctx to d_dst[0], on-stream
+ * (no host round trip): lets a rank publish [count | offsets...] as one fixed-size
+ * slot of an all-gather. */
+int bmx_count_to_device(bmx_ctx *ctx, uint64_t *d_dst, void *stream);
+
+/* After an all-gather of `world` slots of `slot_stride` uint64 each, laid out
+ * [count, offset_0, offset_1, ...]: write the rank-order concatenation of the
+ * valid offsets to d_merged (ascending globally, because shards are contiguous and
+ * each list is ascending) and the total to d_total[0].  Counts larger than
+ * slot_stride-1 are clamped (the caller checks the counts and falls back). */
+int bmx_merge_gathered_device(bmx_ctx *ctx, const uint64_t *d_gathered, int32_t world,
+                              uint64_t slot_stride, uint64_t *d_merged, uint64_t merged_capacity,
+                              uint64_t *d_total, void *stream);
 
 /* Text upload kept apart from the scan (repeated queries on a resident text). */
 int bmx_text_upload(bmx_ctx *ctx, const char *text, uint64_t n, void **d_text_out);

@@ -52,6 +52,29 @@ __global__ __launch_bounds__(SMALL_SORT_THREADS) void small_sort_kernel(uint64_t
 }
 
 // ---------------------------------------------------------------------------
+// Multi-GPU: compaction of all-gathered fixed-size slots [count, offsets...] into
+// the rank-order concatenation.  One workgroup per rank; the exclusive prefix of
+// the (at most a few dozen) counts is recomputed by every workgroup.
+// ---------------------------------------------------------------------------
+__global__ void merge_gathered_kernel(const uint64_t *gathered, int world, uint64_t stride, uint64_t *merged,
+                                      uint64_t merged_cap, uint64_t *total_out)
+{
+    const int r = blockIdx.x;
+    uint64_t before = 0, mine = 0, total = 0;
+    for (int i = 0; i < world; ++i) {
+        uint64_t c = gathered[(uint64_t)i * stride];
+        if (c > stride - 1) c = stride - 1;
+        if (i < r) before += c;
+        if (i == r) mine = c;
+        total += c;
+    }
+    if (r == 0 && threadIdx.x == 0) *total_out = total;
+    const uint64_t *src = gathered + (uint64_t)r * stride + 1;
+    for (uint64_t i = threadIdx.x; i < mine; i += blockDim.x)
+        if (before + i < merged_cap) merged[before + i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
 // Synthetic corpus, SURVEY.md s8(d): counter-based, so host and device, and any
 // shard of the stream, produce identical bytes.
 //   byte i = f((splitmix64(seed + (i >> 3)) >> (8 * (i & 7))) & 0xFF)

@@ -294,6 +294,26 @@ int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_o
     return bmx_search_device_finish(ctx, d_match_positions, capacity, n_matches, stream);
 }
 
+int bmx_count_to_device(bmx_ctx *ctx, uint64_t *d_dst, void *stream_v)
+{
+    if (!ctx || !d_dst) return BMX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(d_dst, ctx->d_count, sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream_v));
+    return BMX_OK;
+}
+
+int bmx_merge_gathered_device(bmx_ctx *ctx, const uint64_t *d_gathered, int32_t world, uint64_t slot_stride,
+                              uint64_t *d_merged, uint64_t merged_capacity, uint64_t *d_total, void *stream_v)
+{
+    if (!ctx || !d_gathered || !d_total || world < 1 || slot_stride < 1) return BMX_ERR_ARG;
+    if (merged_capacity > 0 && !d_merged) return BMX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(bmx::merge_gathered_kernel, dim3(world), dim3(256), 0, (hipStream_t)stream_v, d_gathered,
+                       (int)world, slot_stride, d_merged, merged_capacity, d_total);
+    HIPCHK(hipGetLastError());
+    return BMX_OK;
+}
+
 int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out)
 {
     if (!ctx || !d_ptr_out) return BMX_ERR_ARG;

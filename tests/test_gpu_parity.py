@@ -1,0 +1,336 @@
+"""GPU suite: the HIP path, called through the C ABI (libbmx.so), against the
+oracle, the golden fixtures generated from the reference's own code, and -- at
+BASELINE.json's full sizes -- size-independent properties (every planted offset
+found, nothing else; shard decomposition == unsharded).  Bar: bit-exact."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_file_bytes, load_golden
+from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus, host, shard
+
+pytestmark = pytest.mark.gpu
+
+N_VARIANTS = 8
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def dev_search(ctx, text_np, pat, **kw):
+    """Upload with torch, scan through bmx_search_device, return uint64 numpy."""
+    import torch
+
+    d = torch.from_numpy(np.ascontiguousarray(text_np, dtype=np.uint8)).cuda()
+    out = torch.empty(max(16, len(text_np)), dtype=torch.int64, device="cuda")
+    pos, total = ctx.search_device(d, pat, out=out, **kw)
+    assert total == pos.numel()
+    return pos.cpu().numpy().astype(np.uint64)
+
+
+# ---------------------------------------------------------------- golden fixtures
+def test_small_cases_golden_host_entry_point(ctx):
+    """bmx_search(text, pattern, match_positions): host buffers in and out."""
+    for case in load_golden("small_cases.json")[:160]:
+        got = ctx.search(case["text"], case["pattern"])
+        assert got.tolist() == case["positions"], (case["text"], case["pattern"])
+
+
+def test_small_cases_golden_device_entry_point(ctx):
+    for case in load_golden("small_cases.json")[160:]:
+        t = np.frombuffer(case["text"].encode("latin-1"), dtype=np.uint8)
+        got = dev_search(ctx, t, case["pattern"])
+        assert got.tolist() == case["positions"], (case["text"], case["pattern"])
+
+
+def test_reference_corpora_golden(ctx):
+    cache = {}
+    for case in load_golden("corpora.json"):
+        raw = cache.setdefault(case["file"], golden_file_bytes(case["file"]))
+        got = ctx.search(raw, case["pattern"])
+        assert got.size == case["count"], (case["file"], case["pattern"])
+        assert sha(got) == case["sha256"], (case["file"], case["pattern"])
+
+
+def test_synthetic_recipes_golden_generated_in_hbm(ctx):
+    """Text generated on the device by bmx_gen_text_device/bmx_plant_device, scanned
+    in place; expected offsets come from the reference build (synthetic.json)."""
+    for case in load_golden("synthetic.json"):
+        spec = corpus.CorpusSpec(case["name"], case["n"], case["m"], case["kind"], case["seed"],
+                                 case["plant_period"], case["boundary_period"], case["pattern_from_text"])
+        d_text = spec.device_text(ctx)
+        assert sha(d_text.cpu().numpy()) == case["text_sha256"], case["name"]
+        pos, total = ctx.search_device(d_text, spec.pattern(), capacity=1 << 16)
+        got = pos.cpu().numpy().astype(np.uint64)
+        assert total == case["count"] and sha(got) == case["sha256"], case["name"]
+
+
+def test_ranges_golden_reference_kernel_contract(ctx, port):
+    """bmx_search_ranges == the reference launch (se[2P] in, ans[P] out), with the
+    caller's own tables passed through like clSetKernelArg 4 and 5 do."""
+    raw = golden_file_bytes("input7.txt")
+    for case in load_golden("ranges.json"):
+        tabs = port.tables(case["pattern"])
+        ans = ctx.search_ranges(raw, case["pattern"], case["se"], tables=tabs)
+        assert ans.tolist() == case["ans"], case
+        assert ctx.search_ranges(raw, case["pattern"], case["se"]).tolist() == case["ans"]
+
+
+# ---------------------------------------------------------------- oracle, seeded
+def test_random_texts_vs_oracle_all_variants(ctx, port):
+    rng = np.random.default_rng(2026)
+    try:
+        for v in range(N_VARIANTS):
+            ctx.set_variant(v)
+            for _ in range(12):
+                alpha = int(rng.integers(1, 6))
+                m = int(rng.integers(1, 40))
+                n = int(rng.integers(1, 300000))
+                text = (rng.integers(0, alpha, n) + 97).astype(np.uint8)
+                a = int(rng.integers(0, max(1, n - m)))
+                pat = text[a:a + m].tobytes() if rng.random() < 0.7 else (rng.integers(0, alpha, m) + 97).astype(np.uint8).tobytes()
+                got = dev_search(ctx, text, pat)
+                want = port.search(text, pat)
+                assert np.array_equal(got, want), (v, n, m, alpha)
+    finally:
+        ctx.set_variant(0)
+
+
+def test_printable_texts_vs_oracle(ctx, port):
+    rng = np.random.default_rng(7)
+    for _ in range(20):
+        n = int(rng.integers(1000, 2_000_000))
+        m = int(rng.integers(1, 100))
+        text = (rng.integers(0, 95, n) + 32).astype(np.uint8)
+        pat = text[n // 2:n // 2 + m].copy()
+        for p in rng.integers(0, n - m, 20):  # plant
+            text[p:p + m] = pat
+        got = dev_search(ctx, text, pat.tobytes())
+        assert np.array_equal(got, port.search(text, pat.tobytes()))
+
+
+def test_hit_at_every_offset_around_tile_and_segment_boundaries(ctx, port):
+    """One planted hit at each offset in [boundary - m - 1, boundary + m + 1] for the
+    tile size of every kernel variant (the (m-1)-byte overlap lives in LDS only)."""
+    import torch
+
+    m = 16
+    pat = b"Q" * 15 + b"R"
+    try:
+        for v in range(N_VARIANTS):
+            ctx.set_variant(v)
+            g = ctx.geometry(m)
+            tile, seg = g["tile_bytes"], g["tile_bytes"] // g["block"]
+            n = 3 * tile + 100
+            base = np.full(n, ord("x"), dtype=np.uint8)
+            for boundary in (tile, 2 * tile, seg, 5 * seg, tile + 64 * seg):
+                for delta in range(-m - 1, m + 2):
+                    text = base.copy()
+                    p = boundary + delta
+                    text[p:p + m] = np.frombuffer(pat, dtype=np.uint8)
+                    d = torch.from_numpy(text).cuda()
+                    pos, total = ctx.search_device(d, pat, capacity=64)
+                    assert total == 1 and int(pos[0]) == p, (v, boundary, delta)
+    finally:
+        ctx.set_variant(0)
+
+
+def test_first_and_last_window_and_exact_length(ctx, port):
+    pat = b"needle-needle-16"
+    for n in (16, 17, 31, 32, 33, 33791, 33792, 33793, 33792 + 15, 2 * 33792, 100000):
+        text = np.full(n, ord("."), dtype=np.uint8)
+        text[:16] = np.frombuffer(pat, dtype=np.uint8)
+        text[n - 16:] = np.frombuffer(pat, dtype=np.uint8)
+        got = dev_search(ctx, text, pat)
+        assert np.array_equal(got, port.search(text, pat)), n
+        assert got[-1] == n - 16
+        if n == 16 or n >= 32:  # in between the two copies overlap and only the later one survives
+            assert got[0] == 0
+
+
+def test_degenerate_sizes(ctx):
+    assert ctx.search(b"abc", b"abcd").size == 0   # n < m
+    assert ctx.search(b"", b"a").size == 0
+    assert ctx.search(b"a", b"a").tolist() == [0]
+    assert ctx.search(b"aaaa", b"a").tolist() == [0, 1, 2, 3]   # m == 1: bad table all 1, good loop empty
+    assert ctx.search(b"ab" * 10, b"abab").tolist() == list(range(0, 17, 2))
+
+
+def test_pattern_lengths_1_99_512(ctx, port):
+    rng = np.random.default_rng(11)
+    text = (rng.integers(0, 3, 400000) + 97).astype(np.uint8)
+    for m in (1, 2, 3, 15, 16, 17, 63, 64, 65, 99, 100, 255, 256, 511, 512):
+        pat = text[1234:1234 + m].tobytes()
+        for p in (0, 70000, 399999 - m):
+            text[p:p + m] = np.frombuffer(pat, dtype=np.uint8)
+        assert np.array_equal(dev_search(ctx, text, pat), port.search(text, pat)), m
+
+
+def test_misaligned_device_pointers(ctx, port):
+    """d_text with every alignment 0..15 and base_offset/n_own (shard) semantics."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    text = (rng.integers(0, 2, 150000) + 97).astype(np.uint8)
+    pat = text[500:509].tobytes()
+    d_full = torch.from_numpy(text).cuda()
+    for off in range(0, 17):
+        view = d_full[off:]
+        pos, total = ctx.search_device(view, pat, capacity=1 << 17)
+        want = port.search(text[off:], pat)
+        assert np.array_equal(pos.cpu().numpy().astype(np.uint64), want), off
+    # base_offset is added to every reported position; n_own trims ownership
+    view = d_full[7:100007]
+    pos, _ = ctx.search_device(view, pat, base_offset=1 << 40, n_own=50000, capacity=1 << 17)
+    want = port.search(text[7:100007], pat)
+    want = want[want < 50000] + np.uint64(1 << 40)
+    assert np.array_equal(pos.cpu().numpy().astype(np.uint64), want)
+
+
+def test_dense_hits_take_the_radix_sort_path(ctx, port):
+    """'aaaa...' / 'aa': ~n matches, far beyond the in-LDS sort (8192)."""
+    n = 1_000_000
+    text = np.full(n, ord("a"), dtype=np.uint8)
+    got = dev_search(ctx, text, b"aa")
+    assert np.array_equal(got, np.arange(n - 1, dtype=np.uint64))
+    text[::1000] = ord("b")
+    got = dev_search(ctx, text, b"aaa")
+    assert np.array_equal(got, port.search(text, b"aaa"))
+
+
+def test_sort_sizes_around_the_lds_limit(ctx, port):
+    for hits in (1, 2, 3, 8191, 8192, 8193, 20000):
+        n = hits * 7 + 100
+        text = np.full(n, ord("-"), dtype=np.uint8)
+        text[np.arange(hits) * 7 + 3] = ord("#")
+        got = dev_search(ctx, text, b"#")
+        assert np.array_equal(got, np.arange(hits, dtype=np.uint64) * 7 + 3), hits
+
+
+def test_capacity_overflow_is_a_defined_error(ctx):
+    import ctypes as C
+
+    text = b"ab" * 5000
+    out = np.zeros(100, dtype=np.uint64)
+    total = C.c_uint64(0)
+    buf = C.create_string_buffer(text, len(text))
+    rc = host.lib().bmx_search(ctx._h, C.cast(buf, C.c_void_p), len(text), b"ab", 2,
+                               out.ctypes.data_as(C.POINTER(C.c_uint64)), 100, C.byref(total))
+    assert rc == host.ERR_CAPACITY and total.value == 5000
+    assert np.all(np.diff(out.astype(np.int64)) > 0) and np.all(out % 2 == 0) and out.max() < 10000
+
+
+def test_text_bytes_above_0x7f(ctx, port):
+    rng = np.random.default_rng(5)
+    text = rng.integers(0, 256, 300000).astype(np.uint8)
+    for p in (0, 1000, 299997):
+        text[p:p + 3] = np.frombuffer(b"abc", dtype=np.uint8)
+    for pat in (b"abc", b"a", b"\x00\x00"):
+        assert np.array_equal(dev_search(ctx, text, pat), port.naive(text, pat))
+    with pytest.raises(host.BmxError) as e:
+        ctx.search(text, b"\xff\xfe")
+    assert e.value.rc == host.ERR_DOMAIN
+
+
+def test_caller_tables_are_used_like_the_reference_kernel_uses_them(ctx, port):
+    """The reference passes its own tables into the kernel; any SAFE tables (shift 1
+    everywhere = brute force) must give the same match list."""
+    rng = np.random.default_rng(8)
+    text = (rng.integers(0, 4, 200000) + 65).astype(np.uint8)
+    pat = text[100:112].tobytes()
+    want = port.search(text, pat)
+    bad = np.ones(128, dtype=np.int32)
+    good = np.ones(12, dtype=np.int32)
+    assert np.array_equal(dev_search(ctx, text, pat, tables=(bad, good)), want)
+    assert np.array_equal(dev_search(ctx, text, pat, tables=port.tables(pat)), want)
+
+
+def test_device_generator_matches_host_generator(ctx):
+    import torch
+
+    for kind in (0, 1):
+        for start, length in ((0, 100003), (5, 4096), ((1 << 32) - 100, 300), (12345, 1 << 20)):
+            d = torch.empty(length + 3, dtype=torch.uint8, device="cuda")[3:]  # misaligned destination
+            ctx.gen_text(d, start, 0x5EED0002, kind)
+            assert np.array_equal(d.cpu().numpy(), corpus.stream_bytes(start, length, 0x5EED0002, kind))
+
+
+# ---------------------------------------------------------------- sharding on one GPU
+def test_shard_decomposition_equals_unsharded(ctx, port):
+    spec = corpus.CorpusSpec("shards", 6 * (1 << 20) + 77, 16, 0, 0x5EED0004, 1 << 16, 1 << 18, -1)
+    full = spec.host_text()
+    want = port.search(full, spec.pattern())
+    assert np.array_equal(want, spec.planted_offsets())
+    for world in (1, 2, 4, 8):
+        lists = []
+        for r in range(world):
+            start, length, n_own = shard.shard_extent(spec.n, spec.m, world, r)
+            d = spec.device_text(ctx, start, length)
+            pos, _ = ctx.search_device(d, spec.pattern(), n_own=n_own, base_offset=start, capacity=1 << 16)
+            lists.append(pos.cpu().numpy().astype(np.uint64))
+        assert np.array_equal(shard.merge_shard_lists(lists), want), world
+
+
+# ---------------------------------------------------------------- BASELINE full sizes
+@pytest.mark.parametrize("name", ["cfg2_4GiB_m16", "cfg3_4GiB_m64_acgt", "cfg3b_4GiB_m64_p95"])
+def test_full_size_configs_find_exactly_the_planted_offsets(ctx, port, name):
+    """4 GiB generated in HBM; the expected list is known by construction (plants),
+    and the first and last 64 MiB are also checked byte-for-byte against the oracle."""
+    import torch
+
+    spec = corpus.CONFIGS[name]
+    d_text = spec.device_text(ctx)
+    out = torch.empty(1 << 16, dtype=torch.int64, device="cuda")
+    pos, total = ctx.search_device(d_text, spec.pattern(), out=out)
+    got = pos.cpu().numpy().astype(np.uint64)
+    want = spec.planted_offsets()
+    if spec.pattern_from_text >= 0:
+        want = np.unique(np.concatenate([want, np.array([spec.pattern_from_text], dtype=np.uint64)]))
+    assert total == want.size and np.array_equal(got, want)
+    assert got[0] == 0 and got[-1] == spec.n - spec.m
+    w = 64 << 20
+    for a in (0, spec.n - w):
+        chunk = d_text[a:a + w].cpu().numpy()
+        assert np.array_equal(chunk, spec.host_text(a, w))
+        ow = port.search(chunk, spec.pattern()) + np.uint64(a)
+        assert np.array_equal(ow, got[(got >= a) & (got <= a + w - spec.m)])
+    del d_text
+    torch.cuda.empty_cache()
+
+
+def test_full_size_shard_of_config4(ctx):
+    """Config 4 is 8 x 4 GiB; one GPU can hold any one shard: scan shard 5 (with its
+    halo) of the 32 GiB corpus and compare with the plants that fall inside it."""
+    import torch
+
+    spec = corpus.CONFIGS["cfg4_32GiB_m16"]
+    start, length, n_own = shard.shard_extent(spec.n, spec.m, 8, 5)
+    assert n_own == 4 << 30 and length == n_own + spec.m - 1
+    d_text = spec.device_text(ctx, start, length)
+    pos, total = ctx.search_device(d_text, spec.pattern(), n_own=n_own, base_offset=start, capacity=1 << 16)
+    got = pos.cpu().numpy().astype(np.uint64)
+    want = spec.planted_offsets()
+    want = want[(want >= start) & (want < start + n_own)]
+    assert np.array_equal(got, want)
+    # the forced hit straddling the next shard's boundary belongs to this shard
+    assert (start + n_own - spec.m // 2) in got.tolist()
+    del d_text
+    torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------- C++ driver
+def test_cpp_driver_on_a_reference_corpus_file(ctx, tmp_path):
+    exe = os.path.join(ROOT, "parallel_implementation_of_string_matching_algorithms_opencl_amd", "bin", "bmx_cli")
+    raw = golden_file_bytes("input5L.txt.gz")
+    (tmp_path / "inputEd.txt").write_bytes(raw)
+    (tmp_path / "input1Search.txt").write_bytes(b"occurrences")
+    r = subprocess.run([exe, "--iters", "3", "--positions", "--max-print", "2", "--ranges", "2"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "occurrences: 1098" in r.stdout
+    assert "Found at : 37" in r.stdout
+    assert "Average time" in r.stdout and "process 1 is" in r.stdout

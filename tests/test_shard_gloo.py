@@ -1,0 +1,101 @@
+"""CPU suite, part 3: the N > 1 path -- contiguous shards with an (m-1) halo, the
+ownership rule, and the all-gatherv of match offsets -- over the gloo backend
+with world_size 2 (and 3).  The per-shard scan is done by the oracle here (this
+is a test; the GPU suite runs the same decomposition through the HIP kernel)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus, shard
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, spec_args, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+
+        spec = corpus.CorpusSpec(*spec_args)
+        start, length, n_own = shard.shard_extent(spec.n, spec.m, world, rank)
+        text = spec.host_text(start, length)
+        local = oracle.port().search(text, spec.pattern())
+        local = local[local < n_own] + np.uint64(start)  # ownership: first byte inside the shard
+        t = torch.from_numpy(local.astype(np.int64))
+        merged, counts = shard.allgatherv(t)
+        if rank == 0:
+            q.put((merged.numpy().astype(np.uint64), counts))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_equals_unsharded(world, port):
+    # boundary_period chosen so that forced hits straddle the shard boundaries
+    n = 3 * (1 << 18)
+    spec_args = ("gloo", n, 16, 0, 0x5EED0004, 1 << 14, n // (2 * world) if world == 2 else 1 << 17, -1)
+    spec = corpus.CorpusSpec(*spec_args)
+    want = port.search(spec.host_text(), spec.pattern())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    tcp_port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, tcp_port, spec_args, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    merged, counts = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sum(counts) == want.size
+    assert np.array_equal(merged, want)
+    # a hit that straddles a shard boundary is reported exactly once, by the left shard
+    lo1, _ = shard.shard_bounds(n, world, 1)
+    assert any(p < lo1 < p + 16 for p in want.tolist())
+
+
+def test_shard_bounds_cover_without_overlap():
+    for n in (0, 1, 15, 16, 17, 1000, (1 << 20) + 5, 4 << 30):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = shard.shard_bounds(n, world, r)
+                assert lo == prev and lo <= hi <= n
+                assert lo % 16 == 0 or lo == n
+                prev = hi
+            assert prev == n
+
+
+def test_shard_extent_halo():
+    n, m = 1000, 16
+    for world in (1, 2, 4):
+        for r in range(world):
+            start, length, n_own = shard.shard_extent(n, m, world, r)
+            lo, hi = shard.shard_bounds(n, world, r)
+            assert start == lo and n_own == hi - lo
+            assert length == min(n, hi + m - 1) - lo
+
+
+def test_merge_of_shard_lists_is_sorted(port):
+    spec = corpus.CorpusSpec("merge", 1 << 19, 8, 1, 0x5EED0055, 0, 0, 4000)  # ACGT, m=8: many natural hits
+    text = spec.host_text()
+    want = port.search(text, spec.pattern())
+    assert want.size > 3
+    for world in (1, 2, 4, 8):
+        lists = []
+        for r in range(world):
+            start, length, n_own = shard.shard_extent(spec.n, spec.m, world, r)
+            loc = port.search(text[start:start + length], spec.pattern())
+            lists.append(loc[loc < n_own] + np.uint64(start))
+        assert np.array_equal(shard.merge_shard_lists(lists), want)
