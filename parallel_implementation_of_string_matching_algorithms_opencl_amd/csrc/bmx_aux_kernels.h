@@ -5,28 +5,109 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bmx_scan_kernel.h" // ORDER_BUCKETS, ORDER_BUCKET_CAP
+
 namespace bmx {
 
 // ---------------------------------------------------------------------------
 // Ordering.  The scan appends matches in arrival order; the contract (and the
-// reference's serial run) is ascending order.  Typical results are a few
-// thousand offsets, so one workgroup sorts them in LDS (bitonic network); the
-// count is read on the device so no host round trip sits between scan and
-// sort.  Larger results are left to the radix sort in bmx_sort.hip.
+// reference's serial run) is ascending order.
+//
+// Common case, no sort at all: the scan also drops every match into one of
+// ORDER_BUCKETS position buckets (bucket = shard-local start >> shift, at most
+// ORDER_BUCKET_CAP entries each).  order_kernel -- ONE workgroup, launched right
+// behind the scan, reading the count on the device so that no host round trip
+// sits in between -- takes an exclusive prefix sum over the bucket counts,
+// orders the <= 8 entries of each bucket with a fixed sorting network and
+// writes the ascending list.  It also publishes {count, needs_sort} for the
+// host and re-arms the counters for the next search.
+//
+// Fallback (a bucket overflowed: clustered or dense matches): the unordered list
+// is complete; bmx_search_device_finish() sorts it -- in LDS by the bitonic
+// network below up to 8192 matches, by the radix sort of bmx_sort.hip beyond.
 // ---------------------------------------------------------------------------
+constexpr int ORDER_THREADS = 1024;
+static_assert(ORDER_BUCKETS == ORDER_THREADS * 8, "8 buckets per thread");
+static_assert(ORDER_BUCKET_CAP == 8, "the sorting network below has 8 inputs");
+
+__device__ __forceinline__ void cswap(uint64_t &x, uint64_t &y)
+{
+    const uint64_t lo = x < y ? x : y, hi = x < y ? y : x;
+    x = lo;
+    y = hi;
+}
+
+__global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uint64_t cap,
+                                                              unsigned long long *count, uint32_t *bucket_cnt,
+                                                              const uint64_t *bucket_store,
+                                                              uint32_t *bucket_overflow, uint64_t *status)
+{
+    __shared__ uint32_t wave_total[ORDER_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long total = *count;
+    const bool ordered = out != nullptr && *bucket_overflow == 0 && total <= cap; // block-uniform
+
+    uint4 *cnt4 = reinterpret_cast<uint4 *>(bucket_cnt);
+    const uint4 c0 = cnt4[2 * tid], c1 = cnt4[2 * tid + 1];
+    const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mine += c[j];
+    uint32_t incl = mine; // inclusive scan across the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += v;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads(); // also: every thread has read count/overflow before they are reset below
+
+    if (ordered && total > 0) {
+        uint32_t base = incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) base += wave_total[w];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t nb = c[j];
+            if (nb == 0) continue;
+            const uint64_t *src = bucket_store + ((uint64_t)tid * 8 + j) * ORDER_BUCKET_CAP;
+            if (nb == 1) {
+                out[base] = src[0];
+            } else {
+                uint64_t v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (uint32_t)i < nb ? src[i] : ~0ull;
+                // 19-comparator network for 8 inputs (checked exhaustively by the 0/1 principle)
+                cswap(v[0], v[2]); cswap(v[1], v[3]); cswap(v[4], v[6]); cswap(v[5], v[7]);
+                cswap(v[0], v[4]); cswap(v[1], v[5]); cswap(v[2], v[6]); cswap(v[3], v[7]);
+                cswap(v[0], v[1]); cswap(v[2], v[3]); cswap(v[4], v[5]); cswap(v[6], v[7]);
+                cswap(v[2], v[4]); cswap(v[3], v[5]);
+                cswap(v[1], v[4]); cswap(v[3], v[6]);
+                cswap(v[1], v[2]); cswap(v[3], v[4]); cswap(v[5], v[6]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if ((uint32_t)i < nb) out[base + i] = v[i];
+            }
+            base += nb;
+        }
+    }
+    if (tid == 0) {
+        status[0] = total;
+        status[1] = (out != nullptr && !ordered && total > 1) ? 1 : 0; // the host must sort the unordered list
+        *count = 0;
+        *bucket_overflow = 0;
+    }
+    cnt4[2 * tid] = make_uint4(0, 0, 0, 0);
+    cnt4[2 * tid + 1] = make_uint4(0, 0, 0, 0);
+}
+
 constexpr int SMALL_SORT_MAX = 8192; // 64 KiB of LDS
 constexpr int SMALL_SORT_THREADS = 1024;
 
-__global__ __launch_bounds__(SMALL_SORT_THREADS) void small_sort_kernel(uint64_t *keys,
-                                                                        const unsigned long long *count,
-                                                                        uint64_t cap)
+__global__ __launch_bounds__(SMALL_SORT_THREADS) void small_sort_kernel(uint64_t *keys, uint32_t n)
 {
     extern __shared__ uint4 smem_u4[];
     uint64_t *s = reinterpret_cast<uint64_t *>(smem_u4);
-    unsigned long long n64 = *count;
-    if (n64 > cap) n64 = cap;
-    if (n64 < 2 || n64 > (unsigned long long)SMALL_SORT_MAX) return; // wave-uniform exit
-    const uint32_t n = (uint32_t)n64;
+    if (n < 2 || n > (uint32_t)SMALL_SORT_MAX) return; // uniform exit
     uint32_t np2 = 2;
     while (np2 < n) np2 <<= 1;
 
@@ -34,15 +115,15 @@ __global__ __launch_bounds__(SMALL_SORT_THREADS) void small_sort_kernel(uint64_t
     __syncthreads();
     for (uint32_t k = 2; k <= np2; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = threadIdx.x; i < np2; i += SMALL_SORT_THREADS) {
-                const uint32_t l = i ^ j;
-                if (l > i) {
-                    const uint64_t x = s[i], y = s[l];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) {
-                        s[i] = y;
-                        s[l] = x;
-                    }
+            // thread x handles the pair (i, i | j) with bit j clear in i
+            for (uint32_t x = threadIdx.x; x < (np2 >> 1); x += SMALL_SORT_THREADS) {
+                const uint32_t i = ((x & ~(j - 1)) << 1) | (x & (j - 1));
+                const uint32_t l = i | j;
+                const uint64_t a = s[i], b = s[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    s[i] = b;
+                    s[l] = a;
                 }
             }
             __syncthreads();

@@ -34,6 +34,8 @@
 namespace bmx {
 
 constexpr int MAX_PATTERN = 512; // == BMX_MAX_PATTERN
+constexpr int ORDER_BUCKETS = 8192;
+constexpr int ORDER_BUCKET_CAP = 8;
 
 // Shift tables and pattern travel in the kernel-argument segment (1.8 KiB): no
 // device buffers to keep alive, no copies on the launch path, and every
@@ -55,6 +57,12 @@ struct ScanArgs {
     uint64_t *out;           // match offsets, unordered append (NULL: count only)
     uint64_t cap;            // capacity of out
     unsigned long long *count; // TRUE number of matches (may exceed cap)
+    // Ordering buckets (see order_kernel): bucket b holds the matches whose
+    // shard-local start lies in [b << bucket_shift, (b+1) << bucket_shift).
+    uint32_t *bucket_cnt;    // ORDER_BUCKETS counters
+    uint64_t *bucket_store;  // ORDER_BUCKETS x ORDER_BUCKET_CAP offsets
+    uint32_t *bucket_overflow; // set to 1 when a bucket is full
+    uint32_t bucket_shift;
     uint32_t m;
     uint32_t halo16;         // (m-1) rounded up to a multiple of 16
     ScanTables tab;
@@ -77,7 +85,11 @@ __device__ __forceinline__ void dma16(const uint8_t *gsrc_lane, const uint8_t *l
 }
 
 // Wave-aggregated append of one match per ACTIVE lane (called under divergence).
-__device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t pos)
+// `local` is the match's start relative to text byte 0 of this shard, `pos` the
+// offset to report.  Every match goes to the unordered list (always complete up
+// to cap: the fallback for dense results) and to its position bucket, from which
+// order_kernel writes the ascending list without a sort.
+__device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint64_t pos)
 {
     const uint64_t active = __ballot(1);
     const uint32_t lane = __lane_id();
@@ -87,7 +99,15 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t pos)
     if ((int)lane == leader) base = atomicAdd(a.count, (unsigned long long)__popcll(active));
     base = __shfl(base, leader);
     const uint64_t slot = base + rank;
-    if (a.out != nullptr && slot < a.cap) a.out[slot] = pos;
+    if (a.out != nullptr) {
+        if (slot < a.cap) a.out[slot] = pos;
+        const uint32_t b = (uint32_t)(local >> a.bucket_shift);
+        const uint32_t s = atomicAdd(&a.bucket_cnt[b], 1u);
+        if (s < (uint32_t)ORDER_BUCKET_CAP)
+            a.bucket_store[(uint64_t)b * ORDER_BUCKET_CAP + s] = pos;
+        else
+            *a.bucket_overflow = 1u;
+    }
 }
 
 template <int BLOCK, int SEG>
@@ -172,7 +192,8 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
                 uint32_t k = 1; // kernel1.cl:20-22
                 while (k < m && T[i - k] == s_pat[m - 1 - k]) ++k;
                 if (k == m) { // kernel1.cl:24
-                    emit_hit(a, tile_off + (uint64_t)(i - (m - 1)) + a.out_bias);
+                    const uint64_t astart = tile_off + (uint64_t)(i - (m - 1)); // aligned coordinate
+                    emit_hit(a, astart - a.first, astart + a.out_bias);
                     i += 1;
                     continue;
                 }

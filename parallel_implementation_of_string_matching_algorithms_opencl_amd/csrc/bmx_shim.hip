@@ -15,8 +15,9 @@
 #include <cstring>
 #include <vector>
 
-#include "bmx_aux_kernels.h"
 #include "bmx_scan_kernel.h"
+
+#include "bmx_aux_kernels.h"
 
 static_assert(bmx::MAX_PATTERN == BMX_MAX_PATTERN, "header and kernel disagree");
 
@@ -72,8 +73,13 @@ struct bmx_ctx {
     int num_cu = 256;
     int variant = 0;
     int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
-    unsigned long long *d_count = nullptr;
-    unsigned long long *h_count = nullptr; // pinned
+    unsigned long long *d_count = nullptr; // live match counter; re-armed by order_kernel
+    uint32_t *d_bucket_cnt = nullptr;      // ORDER_BUCKETS, re-armed by order_kernel
+    uint64_t *d_bucket_store = nullptr;    // ORDER_BUCKETS x ORDER_BUCKET_CAP
+    uint32_t *d_overflow = nullptr;
+    uint64_t *d_status = nullptr;          // {count, needs_sort} of the last search
+    uint64_t *h_status = nullptr;          // pinned mirror
+    bool armed = false;                    // counters known to be zero
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int lds_attr_set[N_VARIANTS] = {};
@@ -148,7 +154,12 @@ int bmx_ctx_create(int device, bmx_ctx **out)
         ctx->num_cu = prop.multiProcessorCount;
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc(&ctx->d_count, sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_count, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_bucket_cnt, bmx::ORDER_BUCKETS * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = hipMalloc(&ctx->d_bucket_store, (size_t)bmx::ORDER_BUCKETS * bmx::ORDER_BUCKET_CAP * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_status, 2 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 2 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     if (e != hipSuccess) {
@@ -165,7 +176,11 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_count) (void)hipFree(ctx->d_count);
-    if (ctx->h_count) (void)hipHostFree(ctx->h_count);
+    if (ctx->d_bucket_cnt) (void)hipFree(ctx->d_bucket_cnt);
+    if (ctx->d_bucket_store) (void)hipFree(ctx->d_bucket_store);
+    if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -209,60 +224,74 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     if (n > 0 && !d_text) return BMX_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_v;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned long long), stream));
     ctx->timed = false;
+    if (!ctx->armed) { // first use, or a previous enqueue failed half way: zero the device counters
+        HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned long long), stream));
+        HIPCHK(hipMemsetAsync(ctx->d_bucket_cnt, 0, bmx::ORDER_BUCKETS * sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, sizeof(uint32_t), stream));
+    }
+    ctx->armed = false;
 
     // windows that fit: starts 0 .. n-m; of those the caller owns [0, n_own)
-    if (n < (uint64_t)m) return BMX_OK;
-    const uint64_t n_starts = std::min<uint64_t>(n - (uint64_t)m + 1, n_own);
-    if (n_starts == 0) return BMX_OK;
+    const uint64_t n_starts = n < (uint64_t)m ? 0 : std::min<uint64_t>(n - (uint64_t)m + 1, n_own);
+    uint64_t *out = capacity ? d_match_positions : nullptr;
 
-    const Variant &v = g_variants[ctx->variant];
-    const uint64_t tile = (uint64_t)v.block * v.seg;
-    const uintptr_t addr = (uintptr_t)d_text;
-    const uint64_t mis = addr & 15u;
+    if (n_starts > 0) {
+        const Variant &v = g_variants[ctx->variant];
+        const uint64_t tile = (uint64_t)v.block * v.seg;
+        const uintptr_t addr = (uintptr_t)d_text;
+        const uint64_t mis = addr & 15u;
 
-    bmx::ScanArgs a;
-    int rc = fill_tables(a.tab, pat, m, good, bad);
-    if (rc != BMX_OK) return rc;
-    a.text16 = (const uint8_t *)(addr - mis);
-    a.first = mis;
-    a.own_end = mis + n_starts;
-    a.data_end = mis + n;
-    a.out_bias = base_offset - mis;
-    a.tile_begin = 0; // mis < 16 <= tile
-    a.tile_end = (a.own_end + tile - 1) / tile;
-    a.out = capacity ? d_match_positions : nullptr;
-    a.cap = capacity;
-    a.count = ctx->d_count;
-    a.m = (uint32_t)m;
-    a.halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
+        bmx::ScanArgs a;
+        int rc = fill_tables(a.tab, pat, m, good, bad);
+        if (rc != BMX_OK) {
+            ctx->armed = true; // nothing was launched
+            return rc;
+        }
+        a.text16 = (const uint8_t *)(addr - mis);
+        a.first = mis;
+        a.own_end = mis + n_starts;
+        a.data_end = mis + n;
+        a.out_bias = base_offset - mis;
+        a.tile_begin = 0; // mis < 16 <= tile
+        a.tile_end = (a.own_end + tile - 1) / tile;
+        a.out = out;
+        a.cap = capacity;
+        a.count = ctx->d_count;
+        a.bucket_cnt = ctx->d_bucket_cnt;
+        a.bucket_store = ctx->d_bucket_store;
+        a.bucket_overflow = ctx->d_overflow;
+        a.bucket_shift = 0;
+        while (((n_starts - 1) >> a.bucket_shift) >= (uint64_t)bmx::ORDER_BUCKETS) ++a.bucket_shift;
+        a.m = (uint32_t)m;
+        a.halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
 
-    const uint32_t lds = lds_bytes_for(v, m);
-    if (lds > LDS_PER_CU) {
-        set_err("LDS need %u exceeds %u", lds, LDS_PER_CU);
-        return BMX_ERR_ARG;
-    }
-    if (ctx->lds_attr_set[ctx->variant] < (int)lds) {
-        HIPCHK(hipFuncSetAttribute((const void *)v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ctx->lds_attr_set[ctx->variant] = (int)lds;
-    }
-    const uint64_t ntiles = a.tile_end - a.tile_begin;
-    const uint64_t max_grid = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, max_grid);
+        const uint32_t lds = lds_bytes_for(v, m);
+        if (lds > LDS_PER_CU) {
+            set_err("LDS need %u exceeds %u", lds, LDS_PER_CU);
+            ctx->armed = true;
+            return BMX_ERR_ARG;
+        }
+        if (ctx->lds_attr_set[ctx->variant] < (int)lds) {
+            HIPCHK(hipFuncSetAttribute((const void *)v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ctx->lds_attr_set[ctx->variant] = (int)lds;
+        }
+        const uint64_t ntiles = a.tile_end - a.tile_begin;
+        const uint64_t max_grid = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, max_grid);
 
-    HIPCHK(hipEventRecord(ctx->ev0, stream));
-    hipLaunchKernelGGL(v.kernel, dim3(grid), dim3(v.block), lds, stream, a);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(ctx->ev1, stream));
-    ctx->timed = true;
-
-    if (capacity > 1) {
-        hipLaunchKernelGGL(bmx::small_sort_kernel, dim3(1), dim3(bmx::SMALL_SORT_THREADS),
-                           bmx::SMALL_SORT_MAX * sizeof(uint64_t), stream, d_match_positions, ctx->d_count,
-                           capacity);
+        HIPCHK(hipEventRecord(ctx->ev0, stream));
+        hipLaunchKernelGGL(v.kernel, dim3(grid), dim3(v.block), lds, stream, a);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev1, stream));
+        ctx->timed = true;
     }
+
+    // ascending list from the position buckets, {count, needs_sort} for the host, counters re-armed
+    hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, out, capacity, ctx->d_count,
+                       ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status);
+    HIPCHK(hipGetLastError());
+    ctx->armed = true;
     return BMX_OK;
 }
 
@@ -272,14 +301,23 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
     if (!ctx) return BMX_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_v;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemcpyAsync(ctx->h_count, ctx->d_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_status, ctx->d_status, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    const uint64_t total = *ctx->h_count;
+    const uint64_t total = ctx->h_status[0];
+    const bool needs_sort = ctx->h_status[1] != 0;
     if (n_matches) *n_matches = total;
     const uint64_t stored = std::min(total, capacity);
-    if (stored > (uint64_t)bmx::SMALL_SORT_MAX) {
-        int rc = bmx_internal_radix_sort(d_match_positions, stored, stream, g_err, sizeof g_err);
-        if (rc != BMX_OK) return rc;
+    if (needs_sort && stored > 1 && d_match_positions) {
+        // a position bucket overflowed (clustered / dense matches): order the complete unordered list
+        if (stored <= (uint64_t)bmx::SMALL_SORT_MAX) {
+            hipLaunchKernelGGL(bmx::small_sort_kernel, dim3(1), dim3(bmx::SMALL_SORT_THREADS),
+                               bmx::SMALL_SORT_MAX * sizeof(uint64_t), stream, d_match_positions, (uint32_t)stored);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(stream));
+        } else {
+            int rc = bmx_internal_radix_sort(d_match_positions, stored, stream, g_err, sizeof g_err);
+            if (rc != BMX_OK) return rc;
+        }
     }
     return total > capacity && capacity > 0 ? BMX_ERR_CAPACITY : BMX_OK;
 }
@@ -298,7 +336,7 @@ int bmx_count_to_device(bmx_ctx *ctx, uint64_t *d_dst, void *stream_v)
 {
     if (!ctx || !d_dst) return BMX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemcpyAsync(d_dst, ctx->d_count, sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream_v));
+    HIPCHK(hipMemcpyAsync(d_dst, ctx->d_status, sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream_v));
     return BMX_OK;
 }
 

@@ -211,6 +211,22 @@ def test_sort_sizes_around_the_lds_limit(ctx, port):
         assert np.array_equal(got, np.arange(hits, dtype=np.uint64) * 7 + 3), hits
 
 
+def test_clustered_hits_overflow_the_position_buckets(ctx, port):
+    """Matches packed into a small part of a large text overflow their position
+    bucket (8 entries): the ordered list must then come from the fallback sorts
+    (in-LDS bitonic up to 8192 matches, radix beyond)."""
+    for hits in (9, 100, 5000, 8192, 8193, 30000):
+        n = 4 << 20
+        text = np.full(n, ord("-"), dtype=np.uint8)
+        where = 1000 + np.arange(hits) * 3
+        text[where] = ord("#")
+        text[n - 1] = ord("#")
+        got = dev_search(ctx, text, b"#")
+        assert np.array_equal(got, np.concatenate([where, [n - 1]]).astype(np.uint64)), hits
+    # and the next search on the same context starts from clean counters
+    assert dev_search(ctx, np.frombuffer(b"..#..", dtype=np.uint8), b"#").tolist() == [2]
+
+
 def test_capacity_overflow_is_a_defined_error(ctx):
     import ctypes as C
 
