@@ -206,7 +206,7 @@ def main():
                    "pattern_bytes": m, "alphabet": "printable-95" if spec.kind == 0 else "ACGT",
                    "matches": int(result.size), "sharding": f"{world} contiguous shard(s) + {m - 1} B halo",
                    "exchange": "RCCL all-gather of [count|offsets] slots" if world > 1 else "none",
-                   "kernel": f"scan_kernel<{geom['block']},{geom['tile_bytes'] // geom['block']}> grid {geom['grid']} "
+                   "kernel": f"{geom['kind']} block {geom['block']} seg {geom['seg']} grid {geom['grid']} "
                              f"lds {geom['lds_bytes']}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(args.workload),

@@ -140,9 +140,11 @@ int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out);
 /* Duration of the most recent scan kernel launched through ctx, from HIP events
  * recorded on the launch stream around that kernel alone (ms); < 0 if none. */
 float bmx_last_scan_ms(bmx_ctx *ctx);
-/* Scan-kernel launch geometry actually used: out[0]=grid, out[1]=block,
- * out[2]=tile bytes, out[3]=LDS bytes per workgroup. */
-int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[4]);
+/* Scan-kernel launch geometry for pattern length m: out[0]=grid (workgroups),
+ * out[1]=threads per workgroup, out[2]=window starts per synchronisation unit
+ * (workgroup tile or wave piece), out[3]=LDS bytes per workgroup, out[4]=window
+ * starts per lane, out[5]=kernel kind (0 workgroup tiles, 1 wave streams). */
+int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6]);
 /* Tuning knob for experiments: 0 = default kernel variant. */
 int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu);
 

@@ -79,9 +79,10 @@ __device__ __forceinline__ lds_void *to_lds(const void *p)
 
 // One wave-instruction = 64 lanes x 16 B = 1 KiB from HBM straight into LDS.
 // `lds_wave_base` must be wave-uniform; lane L's 16 bytes land at base + 16*L.
+template <int AUX>
 __device__ __forceinline__ void dma16(const uint8_t *gsrc_lane, const uint8_t *lds_wave_base)
 {
-    __builtin_amdgcn_global_load_lds((gbl_void *)gsrc_lane, to_lds(lds_wave_base), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void *)gsrc_lane, to_lds(lds_wave_base), 16, 0, AUX);
 }
 
 // Wave-aggregated append of one match per ACTIVE lane (called under divergence).
@@ -110,7 +111,12 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint
     }
 }
 
-template <int BLOCK, int SEG>
+// AUX: cache-policy bits of the DMA (0 default, 2 = nt: the text is read once).
+// MODE 0 is the product; MODE 1 (DMA only, no walkers) and MODE 2 (walkers only:
+// each workgroup loads its first two tiles and keeps re-walking them) exist for
+// timing the two halves alone and return wrong match lists.
+// WALK 0: byte-wise walker, any m.  WALK 1: 4-byte tail compare, needs m >= 4.
+template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0>
 __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
 {
     static_assert(SEG % 4 == 0 && (SEG / 4) % 2 == 1, "SEG must be 4 * odd (LDS bank spread)");
@@ -134,10 +140,27 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
     const uint32_t lane = tid & 63;
 
     // text bytes >= 0x80 cannot occur in an ASCII pattern: skip the whole window
-    for (uint32_t i = tid; i < 256; i += BLOCK) s_bad[i] = i < 128 ? a.tab.bad[i] : (uint16_t)m;
+    // WALK 2: the entry of the pattern's last character is 0 ("stop here, compare"),
+    // the classic skip-loop encoding; its real shift stays in the scalar b_last.
+    for (uint32_t i = tid; i < 256; i += BLOCK) {
+        uint16_t v = i < 128 ? a.tab.bad[i] : (uint16_t)m;
+        if (WALK == 2 && i == a.tab.pat[m - 1]) v = 0;
+        s_bad[i] = v;
+    }
     for (uint32_t i = tid; i < m; i += BLOCK) {
         s_good[i] = a.tab.good[i];
         s_pat[i] = a.tab.pat[i];
+    }
+
+    // wave-uniform constants of the WALK 1 fast path (scalar registers)
+    uint32_t p4 = 0, g1 = 0, g2 = 0, g3 = 0, b_last = 0;
+    if (WALK == 2) b_last = a.tab.bad[a.tab.pat[m - 1] & 127];
+    if (WALK >= 1) {
+        p4 = (uint32_t)a.tab.pat[m - 4] | ((uint32_t)a.tab.pat[m - 3] << 8) | ((uint32_t)a.tab.pat[m - 2] << 16) |
+             ((uint32_t)a.tab.pat[m - 1] << 24);
+        g1 = a.tab.good[1];
+        g2 = a.tab.good[2];
+        g3 = a.tab.good[3];
     }
 
     const uint32_t nchunk = buf_bytes >> 4; // 16-B chunks per tile incl. halo
@@ -148,7 +171,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
         for (uint32_t c0 = wave * 64; c0 < nchunk; c0 += BLOCK) {
             const uint32_t c = c0 + lane;
             const uint64_t goff = tile_off + ((uint64_t)c << 4);
-            if (c < nchunk && goff < a.data_end) dma16(gsrc + ((uint64_t)c << 4), dst + ((uint64_t)c0 << 4));
+            if (c < nchunk && goff < a.data_end) dma16<AUX>(gsrc + ((uint64_t)c << 4), dst + ((uint64_t)c0 << 4));
         }
     };
 
@@ -163,7 +186,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
         __syncthreads();
 
         const uint64_t tn = t + gridDim.x;
-        if (tn < a.tile_end) issue_tile(tn, cur ? buf0 : buf1);
+        if (tn < a.tile_end && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x)) issue_tile(tn, cur ? buf0 : buf1);
 
         const uint8_t *T = cur ? buf1 : buf0;
         const uint64_t tile_off = t * (uint64_t)TILE;
@@ -178,28 +201,97 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
         const uint64_t rem = a.own_end - tile_off; // > 0 because t < tile_end
         if (rem < (uint64_t)hi) hi = (uint32_t)rem;
 
-        if (lo < hi) {
-            const uint32_t plast = s_pat[m - 1];
+        if (MODE != 1 && lo < hi) {
             uint32_t i = lo + m - 1;          // index of the window's last character
             const uint32_t ilim = hi + m - 1; // exclusive
-            while (i < ilim) {
-                const uint32_t c = T[i];
-                const uint32_t b = s_bad[c];
-                if (c != plast) { // k == 0: shift = max(bad[c] - 0, 1), kernel1.cl:28,30
-                    i += b;
-                    continue;
+            if (WALK == 2) {
+                // m >= 4.  Skip loop, two windows per round: s_bad[c] is the k == 0 shift
+                // (kernel1.cl:28,30) for every character but the pattern's last one, whose
+                // entry is 0 -- the walker then stays on that window and the second lookup
+                // sees the same 0.  Only windows whose last character matches leave the
+                // loop body's straight line.  The second lookup may run up to m-1 bytes
+                // past the lane's segment (and, for the last lane, past the tile buffer
+                // into the next LDS region): harmless, such a window is never reported.
+                while (i < ilim) {
+                    i += s_bad[T[i]];
+                    const uint32_t b2 = s_bad[T[i]];
+                    i += b2;
+                    if (b2 == 0 && i < ilim) {
+                        // last character equal: k >= 1.  The next three come from three
+                        // independent byte reads; good[1..3] sit in scalar registers.
+                        const uint32_t c1 = T[i - 1], c2 = T[i - 2], c3 = T[i - 3];
+                        const uint32_t diff = (c3 | (c2 << 8) | (c1 << 16)) ^ (p4 & 0x00FFFFFFu);
+                        uint32_t k;
+                        int d2;
+                        if (__builtin_expect(diff == 0, 0)) {
+                            k = 4; // kernel1.cl:20-22, continued byte-wise
+                            while (k < m && T[i - k] == s_pat[m - 1 - k]) ++k;
+                            if (k == m) { // kernel1.cl:24
+                                const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
+                                emit_hit(a, astart - a.first, astart + a.out_bias);
+                                i += 1;
+                                continue;
+                            }
+                            d2 = (int)s_good[k];
+                        } else {
+                            k = (uint32_t)__clz((int)diff) >> 3; // the top byte is 0: 1..3
+                            d2 = k == 1 ? (int)g1 : (k == 2 ? (int)g2 : (int)g3);
+                        }
+                        const int d1 = (int)b_last - (int)k > 1 ? (int)b_last - (int)k : 1; // kernel1.cl:28
+                        i += (uint32_t)(d1 > d2 ? d1 : d2);                                   // kernel1.cl:29-32
+                    }
                 }
-                uint32_t k = 1; // kernel1.cl:20-22
-                while (k < m && T[i - k] == s_pat[m - 1 - k]) ++k;
-                if (k == m) { // kernel1.cl:24
-                    const uint64_t astart = tile_off + (uint64_t)(i - (m - 1)); // aligned coordinate
-                    emit_hit(a, astart - a.first, astart + a.out_bias);
-                    i += 1;
-                    continue;
+            } else if (WALK == 1) {
+                // m >= 4.  One unaligned 4-byte LDS read fetches the window's last four
+                // characters; XOR with the pattern's last four gives k = 0..3 matched
+                // characters without a compare loop (kernel1.cl:20-22), and good[1..3]
+                // sit in scalar registers, so the only other LDS access of a window is
+                // the bad-symbol lookup.  k >= 4 (all four equal) is the rare path.
+                while (i < ilim) {
+                    uint32_t x;
+                    __builtin_memcpy(&x, T + (i - 3), 4); // byte i is the top byte
+                    const uint32_t b = s_bad[x >> 24];
+                    const uint32_t diff = x ^ p4;
+                    if (__builtin_expect(diff == 0, 0)) {
+                        uint32_t k = 4;
+                        while (k < m && T[i - k] == s_pat[m - 1 - k]) ++k;
+                        if (k == m) { // kernel1.cl:24
+                            const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
+                            emit_hit(a, astart - a.first, astart + a.out_bias);
+                            i += 1;
+                            continue;
+                        }
+                        const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1;
+                        const int d2 = (int)s_good[k];
+                        i += (uint32_t)(d1 > d2 ? d1 : d2);
+                        continue;
+                    }
+                    const uint32_t k = (uint32_t)__clz((int)diff) >> 3; // 0..3 equal bytes from the top
+                    const int gk = k == 0 ? 0 : (k == 1 ? (int)g1 : (k == 2 ? (int)g2 : (int)g3));
+                    const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28 (k == 0: b >= 1)
+                    i += (uint32_t)(d1 > gk ? d1 : gk);                       // kernel1.cl:29-32
                 }
-                const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28
-                const int d2 = (int)s_good[k];                              // kernel1.cl:29
-                i += (uint32_t)(d1 > d2 ? d1 : d2);                         // kernel1.cl:31
+            } else {
+                const uint32_t plast = s_pat[m - 1];
+                while (i < ilim) {
+                    const uint32_t c = T[i];
+                    const uint32_t b = s_bad[c];
+                    if (c != plast) { // k == 0: shift = max(bad[c] - 0, 1), kernel1.cl:28,30
+                        i += b;
+                        continue;
+                    }
+                    uint32_t k = 1; // kernel1.cl:20-22
+                    while (k < m && T[i - k] == s_pat[m - 1 - k]) ++k;
+                    if (k == m) { // kernel1.cl:24
+                        const uint64_t astart = tile_off + (uint64_t)(i - (m - 1)); // aligned coordinate
+                        emit_hit(a, astart - a.first, astart + a.out_bias);
+                        i += 1;
+                        continue;
+                    }
+                    const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28
+                    const int d2 = (int)s_good[k];                              // kernel1.cl:29
+                    i += (uint32_t)(d1 > d2 ? d1 : d2);                         // kernel1.cl:31
+                }
             }
         }
         cur ^= 1;

@@ -18,6 +18,7 @@
 #include "bmx_scan_kernel.h"
 
 #include "bmx_aux_kernels.h"
+#include "bmx_scan_wave_kernel.h"
 
 static_assert(bmx::MAX_PATTERN == BMX_MAX_PATTERN, "header and kernel disagree");
 
@@ -45,24 +46,41 @@ void set_err(const char *fmt, ...)
         }                                                                                     \
     } while (0)
 
-// Scan-kernel variants: (threads per workgroup, bytes of window starts per lane).
+// Scan-kernel variants.  kind 0 = workgroup-tile kernel (bmx_scan_kernel.h): `block`
+// threads share a tile of block*seg window starts, two tile buffers, one barrier
+// per tile.  kind 1 = wave-stream kernel (bmx_scan_wave_kernel.h): every wave owns
+// pieces of 64*seg window starts and `nbuf` private buffers, no barrier.
+// kernel_short is the walker used for m < 4 (kind 0 only differs).
 struct Variant {
+    int kind;
     int block;
     int seg;
+    int nbuf;
     void (*kernel)(const bmx::ScanArgs);
+    void (*kernel_short)(const bmx::ScanArgs);
 };
 
-#define BMX_VARIANT(B, S) {B, S, bmx::scan_kernel<B, S>}
+#define BMX_TILE(B, S, AUX, MODE, W) {0, B, S, 2, bmx::scan_kernel<B, S, AUX, MODE, W>, bmx::scan_kernel<B, S, AUX, MODE, 0>}
+#define BMX_WAVE(WV, S, AUX, MODE, D, NB)                                                      \
+    {1, (WV) * 64, S, NB, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>}
 const Variant g_variants[] = {
-    BMX_VARIANT(256, 132), // 0: default
-    BMX_VARIANT(256, 68),  // 1
-    BMX_VARIANT(512, 68),  // 2
-    BMX_VARIANT(256, 260), // 3
-    BMX_VARIANT(512, 132), // 4
-    BMX_VARIANT(1024, 68), // 5
-    BMX_VARIANT(256, 36),  // 6
-    BMX_VARIANT(512, 36),  // 7
+    // products (parity-tested, tests/test_gpu_parity.py)
+    BMX_TILE(1024, 68, 2, 0, 0),    // 0: default -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
+    BMX_TILE(1024, 68, 2, 0, 2),    // 1: same tile, skip-loop walker (2 windows per loop round)
+    BMX_TILE(1024, 52, 2, 0, 0),    // 2
+    BMX_TILE(768, 100, 2, 0, 0),    // 3
+    BMX_TILE(256, 132, 2, 0, 0),    // 4: two workgroups per CU
+    BMX_TILE(256, 132, 0, 0, 0),    // 5: default cache policy -- the first kernel of round 1
+    BMX_WAVE(16, 68, 2, 0, 2, 2),   // 6: wave streams, two buffers per wave, speculation depth 2
+    BMX_WAVE(8, 100, 2, 0, 2, 3),   // 7: wave streams, three buffers per wave
+    BMX_WAVE(12, 68, 2, 0, 1, 3),   // 8: wave streams, no speculation
+    // timing experiments (halves of the kernel in isolation; match lists are NOT valid)
+    BMX_TILE(1024, 68, 2, 1, 0),    // 9: DMA only
+    BMX_TILE(1024, 68, 2, 2, 0),    // 10: walkers only
+    BMX_WAVE(8, 100, 2, 1, 2, 3),   // 11: DMA only, wave streams
+    BMX_WAVE(8, 100, 2, 2, 2, 3),   // 12: walkers only, wave streams
 };
+constexpr int N_PRODUCT_VARIANTS = 9;
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
 
@@ -83,16 +101,19 @@ struct bmx_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int lds_attr_set[N_VARIANTS] = {};
+    int lds_attr_set_short[N_VARIANTS] = {};
 };
 
 namespace {
 
+uint64_t unit_bytes(const Variant &v) { return v.kind == 0 ? (uint64_t)v.block * v.seg : 64ull * v.seg; }
+
 uint32_t lds_bytes_for(const Variant &v, int32_t m)
 {
     const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
-    const uint32_t buf = (uint32_t)v.block * v.seg + halo16;
     const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u);
-    return 2 * buf + tables;
+    if (v.kind == 0) return 2 * ((uint32_t)v.block * v.seg + halo16) + tables;
+    return (uint32_t)(v.block / 64) * v.nbuf * (64u * v.seg + halo16) + tables;
 }
 
 int blocks_per_cu_for(const bmx_ctx *ctx, const Variant &v, int32_t m)
@@ -117,6 +138,8 @@ int fill_tables(bmx::ScanTables &tab, const char *pat, int32_t m, const int32_t 
         bad = own_bad;
     }
     // kernel1.cl:28 clamps (bad - k) to >= 1, and k == 0 uses bad as is
+    for (int i = 0; i < m; ++i) // the kernels index 128-entry tables with pattern characters
+        if ((unsigned char)pat[i] >= BMX_BAD_TABLE_SIZE) return BMX_ERR_DOMAIN;
     for (int c = 0; c < BMX_BAD_TABLE_SIZE; ++c) tab.bad[c] = (uint16_t)std::min(std::max(bad[c], 1), 65535);
     for (int k = 0; k < m; ++k) tab.good[k] = (uint16_t)std::min(std::max(good[k], 0), 65535);
     std::memcpy(tab.pat, pat, (size_t)m);
@@ -189,19 +212,22 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
 int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu)
 {
     if (!ctx || variant < 0 || variant >= N_VARIANTS || blocks_per_cu < 0) return BMX_ERR_ARG;
+    (void)N_PRODUCT_VARIANTS; // variants >= N_PRODUCT_VARIANTS exist for tools/variant_sweep.py only
     ctx->variant = variant;
     ctx->blocks_per_cu = blocks_per_cu;
     return BMX_OK;
 }
 
-int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[4])
+int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6])
 {
     if (!ctx || !out || m < 1 || m > BMX_MAX_PATTERN) return BMX_ERR_ARG;
     const Variant &v = g_variants[ctx->variant];
     out[0] = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
     out[1] = v.block;
-    out[2] = (uint64_t)v.block * v.seg;
+    out[2] = unit_bytes(v);
     out[3] = lds_bytes_for(v, m);
+    out[4] = v.seg;
+    out[5] = v.kind;
     return BMX_OK;
 }
 
@@ -238,7 +264,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
 
     if (n_starts > 0) {
         const Variant &v = g_variants[ctx->variant];
-        const uint64_t tile = (uint64_t)v.block * v.seg;
+        const uint64_t tile = unit_bytes(v);
         const uintptr_t addr = (uintptr_t)d_text;
         const uint64_t mis = addr & 15u;
 
@@ -272,16 +298,19 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
             ctx->armed = true;
             return BMX_ERR_ARG;
         }
-        if (ctx->lds_attr_set[ctx->variant] < (int)lds) {
-            HIPCHK(hipFuncSetAttribute((const void *)v.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            ctx->lds_attr_set[ctx->variant] = (int)lds;
+        auto kernel = m >= 4 ? v.kernel : v.kernel_short;
+        int &attr = m >= 4 ? ctx->lds_attr_set[ctx->variant] : ctx->lds_attr_set_short[ctx->variant];
+        if (attr < (int)lds) {
+            HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = (int)lds;
         }
-        const uint64_t ntiles = a.tile_end - a.tile_begin;
+        uint64_t nblocks = a.tile_end - a.tile_begin; // kind 0: one tile per workgroup at a time
+        if (v.kind == 1) nblocks = (nblocks + v.block / 64 - 1) / (v.block / 64); // one piece per wave
         const uint64_t max_grid = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(ntiles, max_grid);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(nblocks, max_grid);
 
         HIPCHK(hipEventRecord(ctx->ev0, stream));
-        hipLaunchKernelGGL(v.kernel, dim3(grid), dim3(v.block), lds, stream, a);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(v.block), lds, stream, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev1, stream));
         ctx->timed = true;

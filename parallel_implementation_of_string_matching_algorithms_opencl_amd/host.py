@@ -266,9 +266,10 @@ class Context:
         return float(lib().bmx_last_scan_ms(self._h))
 
     def geometry(self, m: int) -> dict:
-        g = (C.c_uint64 * 4)()
+        g = (C.c_uint64 * 6)()
         _check(lib().bmx_scan_geometry(self._h, m, g), "bmx_scan_geometry")
-        return {"grid": int(g[0]), "block": int(g[1]), "tile_bytes": int(g[2]), "lds_bytes": int(g[3])}
+        return {"grid": int(g[0]), "block": int(g[1]), "tile_bytes": int(g[2]), "lds_bytes": int(g[3]),
+                "seg": int(g[4]), "kind": "wave-stream" if g[5] else "workgroup-tile"}
 
     def set_variant(self, variant: int, blocks_per_cu: int = 0):
         _check(lib().bmx_set_variant(self._h, variant, blocks_per_cu), "bmx_set_variant")

@@ -37,6 +37,8 @@ def main():
     pat = spec.pattern()
     out = torch.empty(1 << 20, dtype=torch.int64, device="cuda")
     want = spec.planted_offsets()
+    if spec.pattern_from_text >= 0:
+        want = np.unique(np.concatenate([want, np.array([spec.pattern_from_text], dtype=np.uint64)]))
     variants = [int(v) for v in args.variants.split(",")]
     bpcs = [int(b) for b in args.bpc.split(",")]
     res = {}
