@@ -96,8 +96,10 @@ int bmx_search_ranges(bmx_ctx *ctx, const char *text, uint64_t n, const char *pa
  * bytes up to n may be read: a shard passes n = n_own + (m-1) halo bytes
  * (n_own == n - m + 1 or more means "all of it").
  * `stream` is a hipStream_t used as is (NULL = the null stream).  On return the
- * offsets are sorted ascending in d_match_positions and *n_matches is valid
- * (the call synchronises the stream once). */
+ * offsets are sorted ascending in d_match_positions and *n_matches is valid.
+ * The host waits by polling a pinned status word that the ordering kernel writes
+ * after the list is complete (system-scope release), not by synchronising the
+ * stream: work the caller enqueues on `stream` afterwards is ordered as usual. */
 int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own,
                       uint64_t base_offset, const char *pat, int32_t m, const int32_t *good,
                       const int32_t *bad, uint64_t *d_match_positions, uint64_t capacity,
@@ -140,6 +142,10 @@ int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out);
 /* Duration of the most recent scan kernel launched through ctx, from HIP events
  * recorded on the launch stream around that kernel alone (ms); < 0 if none. */
 float bmx_last_scan_ms(bmx_ctx *ctx);
+/* Durations (ms) of the most recent scan kernels, newest first, from the context's
+ * ring of 64 event pairs: lets a benchmark time K searches without synchronising
+ * on an event inside its timed region.  Returns the number written (<= max_n). */
+int bmx_scan_ms_history(bmx_ctx *ctx, float *ms_out, int32_t max_n);
 /* Scan-kernel launch geometry for pattern length m: out[0]=grid (workgroups),
  * out[1]=threads per workgroup, out[2]=window starts per synchronisation unit
  * (workgroup tile or wave piece), out[3]=LDS bytes per workgroup, out[4]=window

@@ -40,7 +40,8 @@ __device__ __forceinline__ void cswap(uint64_t &x, uint64_t &y)
 __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uint64_t cap,
                                                               unsigned long long *count, uint32_t *bucket_cnt,
                                                               const uint64_t *bucket_store,
-                                                              uint32_t *bucket_overflow, uint64_t *status)
+                                                              uint32_t *bucket_overflow, uint64_t *status,
+                                                              uint64_t *host_status, uint64_t seq)
 {
     __shared__ uint32_t wave_total[ORDER_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,11 +91,17 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
             base += nb;
         }
     }
+    __syncthreads(); // every thread's stores to out[] are issued and acknowledged before the release below
     if (tid == 0) {
+        const uint64_t needs_sort = (out != nullptr && !ordered && total > 1) ? 1 : 0; // host sorts the unordered list
         status[0] = total;
-        status[1] = (out != nullptr && !ordered && total > 1) ? 1 : 0; // the host must sort the unordered list
+        status[1] = needs_sort;
         *count = 0;
         *bucket_overflow = 0;
+        // the host polls host_status[2] (pinned, fine-grained) for this search's sequence number
+        host_status[0] = total;
+        host_status[1] = needs_sort;
+        __hip_atomic_store(&host_status[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     cnt4[2 * tid] = make_uint4(0, 0, 0, 0);
     cnt4[2 * tid + 1] = make_uint4(0, 0, 0, 0);

@@ -96,9 +96,13 @@ struct bmx_ctx {
     uint64_t *d_bucket_store = nullptr;    // ORDER_BUCKETS x ORDER_BUCKET_CAP
     uint32_t *d_overflow = nullptr;
     uint64_t *d_status = nullptr;          // {count, needs_sort} of the last search
-    uint64_t *h_status = nullptr;          // pinned mirror
+    uint64_t *h_status = nullptr;          // pinned, device-visible: {count, needs_sort, seq} written by order_kernel
+    uint64_t *h_status_dev = nullptr;      // device address of h_status
+    uint64_t seq = 0;                      // sequence number of the last enqueue
     bool armed = false;                    // counters known to be zero
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    static constexpr int EV_RING = 64;     // event pairs around the last EV_RING scan kernels
+    hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
+    uint64_t n_timed = 0;                  // scan kernels launched with events so far
     bool timed = false;
     int lds_attr_set[N_VARIANTS] = {};
     int lds_attr_set_short[N_VARIANTS] = {};
@@ -182,9 +186,15 @@ int bmx_ctx_create(int device, bmx_ctx **out)
         e = hipMalloc(&ctx->d_bucket_store, (size_t)bmx::ORDER_BUCKETS * bmx::ORDER_BUCKET_CAP * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_status, 2 * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 2 * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 4 * sizeof(uint64_t), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        std::memset(ctx->h_status, 0, 4 * sizeof(uint64_t));
+        e = hipHostGetDevicePointer((void **)&ctx->h_status_dev, ctx->h_status, 0);
+    }
+    for (int i = 0; i < bmx_ctx::EV_RING && e == hipSuccess; ++i) {
+        e = hipEventCreate(&ctx->ev0[i]);
+        if (e == hipSuccess) e = hipEventCreate(&ctx->ev1[i]);
+    }
     if (e != hipSuccess) {
         set_err("bmx_ctx_create: %s", hipGetErrorString(e));
         bmx_ctx_destroy(ctx);
@@ -204,8 +214,10 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < bmx_ctx::EV_RING; ++i) {
+        if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
+        if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
+    }
     delete ctx;
 }
 
@@ -233,11 +245,22 @@ int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6])
 
 float bmx_last_scan_ms(bmx_ctx *ctx)
 {
-    if (!ctx || !ctx->timed) return -1.0f;
     float ms = -1.0f;
-    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
+    if (!ctx || !ctx->timed || bmx_scan_ms_history(ctx, &ms, 1) != 1) return -1.0f;
     return ms;
+}
+
+int bmx_scan_ms_history(bmx_ctx *ctx, float *ms_out, int32_t max_n)
+{
+    if (!ctx || !ms_out || max_n < 0) return BMX_ERR_ARG;
+    const uint64_t have = std::min<uint64_t>(ctx->n_timed, bmx_ctx::EV_RING);
+    const int n = (int)std::min<uint64_t>(have, (uint64_t)max_n);
+    for (int i = 0; i < n; ++i) { // ms_out[0] = most recent
+        const int slot = (int)((ctx->n_timed - 1 - i) % bmx_ctx::EV_RING);
+        if (hipEventSynchronize(ctx->ev1[slot]) != hipSuccess) return BMX_ERR_HIP;
+        if (hipEventElapsedTime(&ms_out[i], ctx->ev0[slot], ctx->ev1[slot]) != hipSuccess) return BMX_ERR_HIP;
+    }
+    return n;
 }
 
 int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own,
@@ -309,16 +332,19 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         const uint64_t max_grid = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(nblocks, max_grid);
 
-        HIPCHK(hipEventRecord(ctx->ev0, stream));
+        const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
+        HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(v.block), lds, stream, a);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(ctx->ev1, stream));
+        HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
+        ctx->n_timed++;
         ctx->timed = true;
     }
 
     // ascending list from the position buckets, {count, needs_sort} for the host, counters re-armed
     hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, out, capacity, ctx->d_count,
-                       ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status);
+                       ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status, ctx->h_status_dev,
+                       ++ctx->seq);
     HIPCHK(hipGetLastError());
     ctx->armed = true;
     return BMX_OK;
@@ -330,8 +356,29 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
     if (!ctx) return BMX_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_v;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemcpyAsync(ctx->h_status, ctx->d_status, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    // order_kernel stores {count, needs_sort} and then the sequence number straight into
+    // pinned host memory: poll for it instead of paying a D2H copy plus a stream
+    // synchronisation (~25 us) per search.  The stream is queried now and then so that
+    // a failed launch cannot hang the caller.
+    {
+        const uint64_t want = ctx->seq;
+        uint64_t spins = 0;
+        while (__atomic_load_n(&ctx->h_status[2], __ATOMIC_ACQUIRE) != want) {
+            if ((++spins & 0xFFFF) == 0) {
+                hipError_t q = hipStreamQuery(stream);
+                if (q != hipSuccess && q != hipErrorNotReady) {
+                    set_err("scan failed: %s", hipGetErrorString(q));
+                    ctx->armed = false;
+                    return BMX_ERR_HIP;
+                }
+                if (q == hipSuccess && __atomic_load_n(&ctx->h_status[2], __ATOMIC_ACQUIRE) != want) {
+                    set_err("bmx_search_device_finish: nothing enqueued on this stream");
+                    return BMX_ERR_ARG;
+                }
+            }
+            __builtin_ia32_pause();
+        }
+    }
     const uint64_t total = ctx->h_status[0];
     const bool needs_sort = ctx->h_status[1] != 0;
     if (n_matches) *n_matches = total;

@@ -61,6 +61,7 @@ SYMBOLS = [
     ("bmx_device_free", C.c_int, [C.c_void_p, C.c_void_p]),
     ("bmx_device_alloc", C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     ("bmx_last_scan_ms", C.c_float, [C.c_void_p]),
+    ("bmx_scan_ms_history", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
     ("bmx_scan_geometry", C.c_int, [C.c_void_p, C.c_int32, _u64p]),
     ("bmx_set_variant", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("bmx_gen_text_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]),
@@ -238,6 +239,11 @@ class Context:
                                                len(pat), gp, bp, C.c_void_p(out.data_ptr()), out.numel(), stream),
                "bmx_search_device_enqueue")
 
+    def prepare(self, d_text, pattern, out, *, n=None, n_own=None, base_offset=0, tables=None):
+        """Bind every argument of one search once; the returned object's enqueue()/finish()
+        are then single C-ABI calls (for callers that repeat the same query, like bench.py)."""
+        return PreparedSearch(self, d_text, pattern, out, n, n_own, base_offset, tables)
+
     def finish(self, out) -> int:
         import torch
 
@@ -264,6 +270,14 @@ class Context:
 
     def last_scan_ms(self) -> float:
         return float(lib().bmx_last_scan_ms(self._h))
+
+    def scan_ms_history(self, n: int = 64):
+        """Durations (ms) of the most recent scan kernels, newest first (ring of 64)."""
+        buf = (C.c_float * max(n, 1))()
+        got = lib().bmx_scan_ms_history(self._h, buf, n)
+        if got < 0:
+            raise BmxError(got, "bmx_scan_ms_history", lib().bmx_last_error().decode(errors="replace"))
+        return [float(buf[i]) for i in range(got)]
 
     def geometry(self, m: int) -> dict:
         g = (C.c_uint64 * 6)()
@@ -292,6 +306,43 @@ class Context:
         stream = C.c_void_p(torch.cuda.current_stream(d_dst.device).cuda_stream)
         _check(lib().bmx_plant_device(self._h, C.c_void_p(d_dst.data_ptr()), start, length, pat, len(pat),
                                       off.ctypes.data_as(_u64p), off.size, stream), "bmx_plant_device")
+
+
+class PreparedSearch:
+    """(ctx, resident text, pattern, tables, output buffer) with the ctypes marshalling done once."""
+
+    def __init__(self, ctx, d_text, pattern, out, n, n_own, base_offset, tables):
+        import torch
+
+        self.ctx, self.d_text, self.out = ctx, d_text, out  # keep the tensors alive
+        self._pat = _pat_bytes(pattern)
+        n = d_text.numel() if n is None else n
+        n_own = n if n_own is None else n_own
+        gp = bp = None
+        if tables is not None:
+            self._bad = np.ascontiguousarray(tables[0], dtype=np.int32)
+            self._good = np.ascontiguousarray(tables[1], dtype=np.int32)
+            bp, gp = self._bad.ctypes.data_as(_i32p), self._good.ctypes.data_as(_i32p)
+        self._stream = C.c_void_p(torch.cuda.current_stream(d_text.device).cuda_stream)
+        self._enq_args = (ctx._h, C.c_void_p(d_text.data_ptr()), C.c_uint64(n), C.c_uint64(n_own),
+                          C.c_uint64(base_offset), self._pat, C.c_int32(len(self._pat)), gp, bp,
+                          C.c_void_p(out.data_ptr()), C.c_uint64(out.numel()), self._stream)
+        self._total = C.c_uint64(0)
+        self._fin_args = (ctx._h, C.c_void_p(out.data_ptr()), C.c_uint64(out.numel()), C.byref(self._total),
+                          self._stream)
+        self._enq = lib().bmx_search_device_enqueue
+        self._fin = lib().bmx_search_device_finish
+
+    def enqueue(self):
+        rc = self._enq(*self._enq_args)
+        if rc != OK:
+            _check(rc, "bmx_search_device_enqueue")
+
+    def finish(self) -> int:
+        rc = self._fin(*self._fin_args)
+        if rc != OK and rc != ERR_CAPACITY:
+            _check(rc, "bmx_search_device_finish")
+        return int(self._total.value)
 
 
 _default_ctx: Optional[Context] = None
