@@ -131,34 +131,21 @@ def main():
     d_text = spec.device_text(ctx, start, length, device=dev)
     tables = host.build_tables(pat)  # host tables once, like BoyreMoore.cpp:150-190 (outside its timer too)
 
-    buf = torch.zeros(SLOT + 1, dtype=torch.int64, device=dev)  # [count | offsets...]
-    out = buf[1:]
-    gathered = torch.zeros(world * (SLOT + 1), dtype=torch.int64, device=dev) if world > 1 else None
-    merged = torch.zeros(world * SLOT, dtype=torch.int64, device=dev) if world > 1 else None
-    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
     state = {}
+    if world > 1:
+        xchg = shard.SlotExchange(ctx, world, rank, dev, slot=SLOT)  # [count | offsets...] slots over RCCL
+        out = xchg.out
+    else:
+        xchg = None
+        out = torch.zeros(SLOT, dtype=torch.int64, device=dev)
     query = ctx.prepare(d_text, pat, out, n=length, n_own=n_own, base_offset=start, tables=tables)
 
     def step():
-        query.enqueue()
         if world > 1:
-            ctx.count_to_device(buf)
-            dist.all_gather_into_tensor(gathered, buf)
-            ctx.merge_gathered(gathered, world, SLOT + 1, merged, d_total)
-        local_total = query.finish()  # the step's one host wait (polls the pinned status word)
-        if world > 1:
-            total = int(d_total.item())
-            counts = gathered.view(world, SLOT + 1)[:, 0]
-            if local_total > SLOT or int(counts.max().item()) > SLOT:  # dense result: exact two-phase exchange
-                full = torch.empty(local_total, dtype=torch.int64, device=dev)
-                pos, _ = ctx.search_device(d_text, pat, n=length, n_own=n_own, base_offset=start, out=full,
-                                           tables=tables)
-                glob, _ = shard.allgatherv(pos)
-                state["result"] = glob
-            else:
-                state["result"] = merged[:total]
+            state["result"] = xchg.run(query)  # scan + order + all-gather + merge; one stream sync
         else:
-            state["result"] = out[:local_total]
+            query.enqueue()
+            state["result"] = out[:query.finish()]  # the step's one host wait (polls the pinned status word)
 
     def fence():
         if world > 1:

@@ -126,8 +126,9 @@ int bmx_count_to_device(bmx_ctx *ctx, uint64_t *d_dst, void *stream);
 /* After an all-gather of `world` slots of `slot_stride` uint64 each, laid out
  * [count, offset_0, offset_1, ...]: write the rank-order concatenation of the
  * valid offsets to d_merged (ascending globally, because shards are contiguous and
- * each list is ascending) and the total to d_total[0].  Counts larger than
- * slot_stride-1 are clamped (the caller checks the counts and falls back). */
+ * each list is ascending), the total to d_total[0] and the largest per-rank count
+ * as published to d_total[1].  Counts larger than slot_stride-1 are clamped: a
+ * caller that sees d_total[1] > slot_stride-1 falls back to an exact exchange. */
 int bmx_merge_gathered_device(bmx_ctx *ctx, const uint64_t *d_gathered, int32_t world,
                               uint64_t slot_stride, uint64_t *d_merged, uint64_t merged_capacity,
                               uint64_t *d_total, void *stream);
@@ -151,6 +152,10 @@ int bmx_scan_ms_history(bmx_ctx *ctx, float *ms_out, int32_t max_n);
  * (workgroup tile or wave piece), out[3]=LDS bytes per workgroup, out[4]=window
  * starts per lane, out[5]=kernel kind (0 workgroup tiles, 1 wave streams). */
 int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6]);
+/* Diagnostic kernel builds only (variant 15): per-wave s_memtime sums of the last
+ * launch, 8 words per wave {issue, walk, dma_wait, barrier_wait, tiles, 0, 0, 0}.
+ * Returns the number of words copied. */
+int bmx_scan_stamps(bmx_ctx *ctx, uint64_t *out, uint64_t max_words);
 /* Tuning knob for experiments: 0 = default kernel variant. */
 int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu);
 

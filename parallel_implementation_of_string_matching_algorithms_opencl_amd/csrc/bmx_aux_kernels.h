@@ -148,15 +148,19 @@ __global__ void merge_gathered_kernel(const uint64_t *gathered, int world, uint6
                                       uint64_t merged_cap, uint64_t *total_out)
 {
     const int r = blockIdx.x;
-    uint64_t before = 0, mine = 0, total = 0;
+    uint64_t before = 0, mine = 0, total = 0, largest = 0;
     for (int i = 0; i < world; ++i) {
         uint64_t c = gathered[(uint64_t)i * stride];
+        if (c > largest) largest = c;
         if (c > stride - 1) c = stride - 1;
         if (i < r) before += c;
         if (i == r) mine = c;
         total += c;
     }
-    if (r == 0 && threadIdx.x == 0) *total_out = total;
+    if (r == 0 && threadIdx.x == 0) {
+        total_out[0] = total;   // matches in the merged list (clamped slots)
+        total_out[1] = largest; // largest per-rank count as published: > stride-1 means a slot overflowed
+    }
     const uint64_t *src = gathered + (uint64_t)r * stride + 1;
     for (uint64_t i = threadIdx.x; i < mine; i += blockDim.x)
         if (before + i < merged_cap) merged[before + i] = src[i];

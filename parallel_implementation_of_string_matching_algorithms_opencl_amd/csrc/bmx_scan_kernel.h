@@ -63,6 +63,7 @@ struct ScanArgs {
     uint64_t *bucket_store;  // ORDER_BUCKETS x ORDER_BUCKET_CAP offsets
     uint32_t *bucket_overflow; // set to 1 when a bucket is full
     uint32_t bucket_shift;
+    unsigned long long *stamps; // MODE 5 only (diagnostic build): per-wave cycle sums, 8 words per wave
     uint32_t m;
     uint32_t halo16;         // (m-1) rounded up to a multiple of 16
     ScanTables tab;
@@ -115,13 +116,24 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint
 // MODE 0 is the product; MODE 1 (DMA only, no walkers) and MODE 2 (walkers only:
 // each workgroup loads its first two tiles and keeps re-walking them) exist for
 // timing the two halves alone and return wrong match lists.
-// WALK 0: byte-wise walker, any m.  WALK 1: 4-byte tail compare, needs m >= 4.
-template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0>
+// WALK 0: byte-wise walker, any m.  WALK 2: skip-loop walker, needs m >= 4.
+// (A WALK 1 that fetched the last four characters with one unaligned ds_read_b32 was
+// 35 % slower -- unaligned LDS dwords -- and is gone)
+// LOADERS: 0 = every wave issues its share of the tile DMA and then walks.
+// > 0 = the first LOADERS waves of the workgroup ONLY issue DMA and the others ONLY
+// walk.  Measured with the MODE 5 stamps (LOADERS 0, 16 waves): issuing the 68 KiB
+// of a tile occupies the CU's vector-memory pipe for ~1900 cycles, during which no
+// wave has started its walk (a wave's own DMA instructions must be accepted first),
+// and the waves released last make everybody wait at the barrier (~1500 cycles).
+// A dedicated loader wave takes both off the walkers' critical path.
+template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0, int LOADERS = 0>
 __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
 {
     static_assert(SEG % 4 == 0 && (SEG / 4) % 2 == 1, "SEG must be 4 * odd (LDS bank spread)");
     static_assert(BLOCK % 64 == 0, "whole waves");
-    constexpr uint32_t TILE = BLOCK * SEG;
+    static_assert(LOADERS >= 0 && LOADERS * 64 < BLOCK, "");
+    constexpr uint32_t WALKERS = BLOCK - 64 * LOADERS; // lanes that walk
+    constexpr uint32_t TILE = WALKERS * SEG;
     static_assert(TILE % 16 == 0, "tiles start on 16-B chunks");
 
     const ScanArgs &a = a_in;
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
     // wave-uniform constants of the WALK 1 fast path (scalar registers)
     uint32_t p4 = 0, g1 = 0, g2 = 0, g3 = 0, b_last = 0;
     if (WALK == 2) b_last = a.tab.bad[a.tab.pat[m - 1] & 127];
-    if (WALK >= 1) {
+    if (WALK == 2) {
         p4 = (uint32_t)a.tab.pat[m - 4] | ((uint32_t)a.tab.pat[m - 3] << 8) | ((uint32_t)a.tab.pat[m - 2] << 16) |
              ((uint32_t)a.tab.pat[m - 1] << 24);
         g1 = a.tab.good[1];
@@ -167,32 +179,64 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
     auto issue_tile = [&](uint64_t t, uint8_t *dst) {
         const uint64_t tile_off = t * (uint64_t)TILE;
         const uint8_t *gsrc = a.text16 + tile_off;
-        // wave w takes chunks [64w, 64w+64), then strides by BLOCK
-        for (uint32_t c0 = wave * 64; c0 < nchunk; c0 += BLOCK) {
+        // issuing wave w takes chunks [64w, 64w+64), then strides by the number of issuing lanes
+        constexpr uint32_t ISSUERS = LOADERS ? 64 * LOADERS : BLOCK;
+        for (uint32_t c0 = wave * 64; c0 < nchunk; c0 += ISSUERS) {
             const uint32_t c = c0 + lane;
             const uint64_t goff = tile_off + ((uint64_t)c << 4);
             if (c < nchunk && goff < a.data_end) dma16<AUX>(gsrc + ((uint64_t)c << 4), dst + ((uint64_t)c0 << 4));
         }
     };
 
+    const bool is_loader = LOADERS > 0 && wave < (uint32_t)LOADERS; // wave-uniform
+    const bool issues = LOADERS == 0 || is_loader;
+    const uint32_t wtid = tid - 64 * LOADERS; // walker lane index (meaningless for loaders)
     uint64_t t = a.tile_begin + blockIdx.x;
-    if (t < a.tile_end) issue_tile(t, buf0);
+    if (t < a.tile_end && issues) issue_tile(t, buf0);
     uint32_t cur = 0;
+    // MODE 5: where does a tile period go?  s_memtime stamps, summed per wave (the
+    // run time of this build means nothing; read the SHARES).
+    unsigned long long st_issue = 0, st_walk = 0, st_dma = 0, st_bar = 0, st_n = 0, st_prev = 0;
+    auto stamp = [&]() -> unsigned long long {
+        if (MODE != 5) return 0;
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long v = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): s_memtime has returned
+        __builtin_amdgcn_sched_barrier(0);
+        return v;
+    };
+    st_prev = stamp();
 
     for (; t < a.tile_end; t += gridDim.x) {
         // (A) this tile's DMA has landed for every wave, and every wave has
         //     finished walking the other buffer, which is refilled next.
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
+        if (MODE == 5) {
+            const unsigned long long x = stamp();
+            st_dma += x - st_prev;
+            st_prev = x;
+        }
         __syncthreads();
+        if (MODE == 5) {
+            const unsigned long long x = stamp();
+            st_bar += x - st_prev;
+            st_prev = x;
+        }
 
         const uint64_t tn = t + gridDim.x;
-        if (tn < a.tile_end && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x)) issue_tile(tn, cur ? buf0 : buf1);
+        if (issues && tn < a.tile_end && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x))
+            issue_tile(tn, cur ? buf0 : buf1);
 
+        if (MODE == 5) {
+            const unsigned long long x = stamp();
+            st_issue += x - st_prev;
+            st_prev = x;
+        }
         const uint8_t *T = cur ? buf1 : buf0;
         const uint64_t tile_off = t * (uint64_t)TILE;
 
         // this lane's window starts, tile-local: [lo, hi)
-        uint32_t lo = tid * SEG;
+        uint32_t lo = wtid * SEG;
         uint32_t hi = lo + SEG;
         if (tile_off < a.first) {
             const uint32_t f = (uint32_t)(a.first - tile_off);
@@ -201,7 +245,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
         const uint64_t rem = a.own_end - tile_off; // > 0 because t < tile_end
         if (rem < (uint64_t)hi) hi = (uint32_t)rem;
 
-        if (MODE != 1 && lo < hi) {
+        if (MODE != 1 && !is_loader && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi) {
             uint32_t i = lo + m - 1;          // index of the window's last character
             const uint32_t ilim = hi + m - 1; // exclusive
             if (WALK == 2) {
@@ -241,36 +285,6 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
                         i += (uint32_t)(d1 > d2 ? d1 : d2);                                   // kernel1.cl:29-32
                     }
                 }
-            } else if (WALK == 1) {
-                // m >= 4.  One unaligned 4-byte LDS read fetches the window's last four
-                // characters; XOR with the pattern's last four gives k = 0..3 matched
-                // characters without a compare loop (kernel1.cl:20-22), and good[1..3]
-                // sit in scalar registers, so the only other LDS access of a window is
-                // the bad-symbol lookup.  k >= 4 (all four equal) is the rare path.
-                while (i < ilim) {
-                    uint32_t x;
-                    __builtin_memcpy(&x, T + (i - 3), 4); // byte i is the top byte
-                    const uint32_t b = s_bad[x >> 24];
-                    const uint32_t diff = x ^ p4;
-                    if (__builtin_expect(diff == 0, 0)) {
-                        uint32_t k = 4;
-                        while (k < m && T[i - k] == s_pat[m - 1 - k]) ++k;
-                        if (k == m) { // kernel1.cl:24
-                            const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-                            emit_hit(a, astart - a.first, astart + a.out_bias);
-                            i += 1;
-                            continue;
-                        }
-                        const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1;
-                        const int d2 = (int)s_good[k];
-                        i += (uint32_t)(d1 > d2 ? d1 : d2);
-                        continue;
-                    }
-                    const uint32_t k = (uint32_t)__clz((int)diff) >> 3; // 0..3 equal bytes from the top
-                    const int gk = k == 0 ? 0 : (k == 1 ? (int)g1 : (k == 2 ? (int)g2 : (int)g3));
-                    const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28 (k == 0: b >= 1)
-                    i += (uint32_t)(d1 > gk ? d1 : gk);                       // kernel1.cl:29-32
-                }
             } else {
                 const uint32_t plast = s_pat[m - 1];
                 while (i < ilim) {
@@ -294,7 +308,21 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
                 }
             }
         }
+        if (MODE == 5) {
+            const unsigned long long x = stamp();
+            st_walk += x - st_prev;
+            st_prev = x;
+            ++st_n;
+        }
         cur ^= 1;
+    }
+    if (MODE == 5 && a.stamps != nullptr && lane == 0) {
+        unsigned long long *o = a.stamps + ((uint64_t)blockIdx.x * (BLOCK / 64) + wave) * 8;
+        o[0] = st_issue;
+        o[1] = st_walk;
+        o[2] = st_dma;
+        o[3] = st_bar;
+        o[4] = st_n;
     }
 }
 

@@ -18,6 +18,7 @@
 #include "bmx_scan_kernel.h"
 
 #include "bmx_aux_kernels.h"
+#include "bmx_scan_ring_kernel.h"
 #include "bmx_scan_wave_kernel.h"
 
 static_assert(bmx::MAX_PATTERN == BMX_MAX_PATTERN, "header and kernel disagree");
@@ -56,31 +57,45 @@ struct Variant {
     int block;
     int seg;
     int nbuf;
+    int loaders; // kind 0: waves that only issue DMA
+    bool stamps; // diagnostic build that writes s_memtime sums (bmx_scan_stamps)
     void (*kernel)(const bmx::ScanArgs);
     void (*kernel_short)(const bmx::ScanArgs);
 };
 
-#define BMX_TILE(B, S, AUX, MODE, W) {0, B, S, 2, bmx::scan_kernel<B, S, AUX, MODE, W>, bmx::scan_kernel<B, S, AUX, MODE, 0>}
+#define BMX_TILE(B, S, AUX, MODE, W) BMX_TILE_L(B, S, AUX, MODE, W, 0)
+#define BMX_TILE_L(B, S, AUX, MODE, W, L) \
+    {0, B, S, 2, L, (MODE) == 5, bmx::scan_kernel<B, S, AUX, MODE, W, L>, bmx::scan_kernel<B, S, AUX, MODE, 0, L>}
+#define BMX_RING(B, S, AUX, SKIP, MODE) BMX_RING_P(B, S, AUX, SKIP, MODE, 0)
+#define BMX_RING_P(B, S, AUX, SKIP, MODE, P) \
+    {2, B, S, 3, 0, (MODE) == 5, bmx::scan_ring_kernel<B, S, AUX, SKIP, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, false, MODE, P>}
 #define BMX_WAVE(WV, S, AUX, MODE, D, NB)                                                      \
-    {1, (WV) * 64, S, NB, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>}
+    {1, (WV) * 64, S, NB, 0, false, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>}
 const Variant g_variants[] = {
-    // products (parity-tested, tests/test_gpu_parity.py)
-    BMX_TILE(1024, 68, 2, 0, 0),    // 0: default -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
-    BMX_TILE(1024, 68, 2, 0, 2),    // 1: same tile, skip-loop walker (2 windows per loop round)
-    BMX_TILE(1024, 52, 2, 0, 0),    // 2
-    BMX_TILE(768, 100, 2, 0, 0),    // 3
-    BMX_TILE(256, 132, 2, 0, 0),    // 4: two workgroups per CU
-    BMX_TILE(256, 132, 0, 0, 0),    // 5: default cache policy -- the first kernel of round 1
-    BMX_WAVE(16, 68, 2, 0, 2, 2),   // 6: wave streams, two buffers per wave, speculation depth 2
-    BMX_WAVE(8, 100, 2, 0, 2, 3),   // 7: wave streams, three buffers per wave
-    BMX_WAVE(12, 68, 2, 0, 1, 3),   // 8: wave streams, no speculation
-    // timing experiments (halves of the kernel in isolation; match lists are NOT valid)
-    BMX_TILE(1024, 68, 2, 1, 0),    // 9: DMA only
-    BMX_TILE(1024, 68, 2, 2, 0),    // 10: walkers only
-    BMX_WAVE(8, 100, 2, 1, 2, 3),   // 11: DMA only, wave streams
-    BMX_WAVE(8, 100, 2, 2, 2, 3),   // 12: walkers only, wave streams
+    // ---- products (every one parity-tested by tests/test_gpu_parity.py) ----
+    BMX_TILE(1024, 68, 2, 0, 0),        // 0: default -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
+    BMX_TILE(1024, 68, 2, 0, 2),        // 1: same tile, skip-loop walker (picked automatically for small alphabets)
+    BMX_TILE(1024, 52, 2, 0, 0),        // 2
+    BMX_TILE(768, 100, 2, 0, 0),        // 3
+    BMX_TILE(256, 132, 2, 0, 0),        // 4: two workgroups per CU
+    BMX_TILE(256, 132, 0, 0, 0),        // 5: default cache policy -- the first kernel of round 1
+    BMX_WAVE(16, 68, 2, 0, 2, 2),       // 6: wave streams, two buffers per wave, speculation depth 2
+    BMX_WAVE(8, 100, 2, 0, 2, 3),       // 7: wave streams, three buffers per wave
+    BMX_WAVE(12, 68, 2, 0, 1, 3),       // 8: wave streams, no speculation
+    BMX_RING(1024, 52, 2, false, 0),    // 9: three-buffer ring, walk then issue
+    BMX_RING(1024, 52, 2, true, 0),     // 10: ring, skip-loop walker
+    BMX_TILE_L(1024, 76, 2, 0, 0, 2),   // 11: 2 loader waves + 14 walker waves
+    // ---- timing experiments (parts of the kernel in isolation; match lists are NOT valid) ----
+    BMX_TILE(1024, 68, 2, 1, 0),        // 12: DMA only
+    BMX_TILE(1024, 68, 2, 2, 0),        // 13: walkers only
+    BMX_TILE(1024, 68, 2, 5, 0),        // 14: s_memtime stamps per tile phase (valid matches; bmx_scan_stamps)
+    BMX_RING(1024, 52, 2, false, 5),    // 15: stamps, ring kernel
+    BMX_WAVE(8, 100, 2, 1, 2, 3),       // 16: DMA only, wave streams
+    BMX_WAVE(8, 100, 2, 2, 2, 3),       // 17: walkers only, wave streams
+    BMX_TILE(1024, 68, 2, 3, 0),        // 18: only wave 0 of each workgroup walks
+    BMX_TILE_L(1024, 68, 2, 1, 0, 1),   // 19: DMA only through ONE loader wave
 };
-constexpr int N_PRODUCT_VARIANTS = 9;
+constexpr int N_PRODUCT_VARIANTS = 12;
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
 
@@ -90,6 +105,7 @@ struct bmx_ctx {
     int device = 0;
     int num_cu = 256;
     int variant = 0;
+    bool auto_walker = true; // until bmx_set_variant(): variant 0 or 1 by the pattern's alphabet
     int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
     unsigned long long *d_count = nullptr; // live match counter; re-armed by order_kernel
     uint32_t *d_bucket_cnt = nullptr;      // ORDER_BUCKETS, re-armed by order_kernel
@@ -99,6 +115,8 @@ struct bmx_ctx {
     uint64_t *h_status = nullptr;          // pinned, device-visible: {count, needs_sort, seq} written by order_kernel
     uint64_t *h_status_dev = nullptr;      // device address of h_status
     uint64_t seq = 0;                      // sequence number of the last enqueue
+    unsigned long long *d_stamps = nullptr; // diagnostic builds only (bmx_scan_stamps)
+    uint64_t stamp_words = 0;
     bool armed = false;                    // counters known to be zero
     static constexpr int EV_RING = 64;     // event pairs around the last EV_RING scan kernels
     hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
@@ -110,13 +128,16 @@ struct bmx_ctx {
 
 namespace {
 
-uint64_t unit_bytes(const Variant &v) { return v.kind == 0 ? (uint64_t)v.block * v.seg : 64ull * v.seg; }
+uint64_t unit_bytes(const Variant &v)
+{
+    return v.kind != 1 ? (uint64_t)(v.block - 64 * v.loaders) * v.seg : 64ull * v.seg;
+}
 
 uint32_t lds_bytes_for(const Variant &v, int32_t m)
 {
     const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
     const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u);
-    if (v.kind == 0) return 2 * ((uint32_t)v.block * v.seg + halo16) + tables;
+    if (v.kind != 1) return (uint32_t)v.nbuf * ((uint32_t)unit_bytes(v) + halo16) + tables;
     return (uint32_t)(v.block / 64) * v.nbuf * (64u * v.seg + halo16) + tables;
 }
 
@@ -127,6 +148,24 @@ int blocks_per_cu_for(const bmx_ctx *ctx, const Variant &v, int32_t m)
     int b = std::max(1, std::min(by_lds, by_waves));
     if (ctx->blocks_per_cu > 0) b = std::min(b, ctx->blocks_per_cu);
     return b;
+}
+
+// Default walker choice.  On small alphabets (DNA: 4 symbols) almost every window ends in
+// a character of the pattern, shifts are a few bytes and the skip-loop walker is 1.7x
+// faster (2.06 vs 1.2 TB/s on 4 GiB ACGT, m = 64); on wide alphabets the byte-wise walker
+// is ~2 % ahead.  The text is unknown here, the pattern's own alphabet is the hint.
+int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m)
+{
+    if (!ctx->auto_walker) return ctx->variant;
+    if (m < 4) return 0;
+    bool seen[256] = {};
+    int distinct = 0;
+    for (int i = 0; i < m; ++i)
+        if (!seen[(unsigned char)pat[i]]) {
+            seen[(unsigned char)pat[i]] = true;
+            ++distinct;
+        }
+    return distinct <= 8 ? 1 : 0;
 }
 
 // Convert the caller's int32 tables (or build them) into the kernel-argument layout.
@@ -213,6 +252,7 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (ctx->d_bucket_store) (void)hipFree(ctx->d_bucket_store);
     if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (int i = 0; i < bmx_ctx::EV_RING; ++i) {
         if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
@@ -226,6 +266,7 @@ int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu)
     if (!ctx || variant < 0 || variant >= N_VARIANTS || blocks_per_cu < 0) return BMX_ERR_ARG;
     (void)N_PRODUCT_VARIANTS; // variants >= N_PRODUCT_VARIANTS exist for tools/variant_sweep.py only
     ctx->variant = variant;
+    ctx->auto_walker = false;
     ctx->blocks_per_cu = blocks_per_cu;
     return BMX_OK;
 }
@@ -286,7 +327,8 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     uint64_t *out = capacity ? d_match_positions : nullptr;
 
     if (n_starts > 0) {
-        const Variant &v = g_variants[ctx->variant];
+        const int vi = pick_variant(ctx, pat, m);
+        const Variant &v = g_variants[vi];
         const uint64_t tile = unit_bytes(v);
         const uintptr_t addr = (uintptr_t)d_text;
         const uint64_t mis = addr & 15u;
@@ -311,6 +353,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         a.bucket_store = ctx->d_bucket_store;
         a.bucket_overflow = ctx->d_overflow;
         a.bucket_shift = 0;
+        a.stamps = nullptr;
         while (((n_starts - 1) >> a.bucket_shift) >= (uint64_t)bmx::ORDER_BUCKETS) ++a.bucket_shift;
         a.m = (uint32_t)m;
         a.halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
@@ -322,7 +365,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
             return BMX_ERR_ARG;
         }
         auto kernel = m >= 4 ? v.kernel : v.kernel_short;
-        int &attr = m >= 4 ? ctx->lds_attr_set[ctx->variant] : ctx->lds_attr_set_short[ctx->variant];
+        int &attr = m >= 4 ? ctx->lds_attr_set[vi] : ctx->lds_attr_set_short[vi];
         if (attr < (int)lds) {
             HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = (int)lds;
@@ -333,6 +376,16 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         const uint32_t grid = (uint32_t)std::min<uint64_t>(nblocks, max_grid);
 
         const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
+        if (v.stamps) { // diagnostic build: room for 8 words per wave
+            const uint64_t words = (uint64_t)grid * (v.block / 64) * 8;
+            if (ctx->stamp_words < words) {
+                if (ctx->d_stamps) HIPCHK(hipFree(ctx->d_stamps));
+                HIPCHK(hipMalloc(&ctx->d_stamps, words * sizeof(unsigned long long)));
+                ctx->stamp_words = words;
+            }
+            HIPCHK(hipMemsetAsync(ctx->d_stamps, 0, words * sizeof(unsigned long long), stream));
+            a.stamps = ctx->d_stamps;
+        }
         HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(v.block), lds, stream, a);
         HIPCHK(hipGetLastError());
@@ -426,6 +479,15 @@ int bmx_merge_gathered_device(bmx_ctx *ctx, const uint64_t *d_gathered, int32_t 
                        (int)world, slot_stride, d_merged, merged_capacity, d_total);
     HIPCHK(hipGetLastError());
     return BMX_OK;
+}
+
+int bmx_scan_stamps(bmx_ctx *ctx, uint64_t *out, uint64_t max_words)
+{
+    if (!ctx || !out) return BMX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t n = std::min(max_words, ctx->stamp_words);
+    if (n) HIPCHK(hipMemcpy(out, ctx->d_stamps, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return (int)std::min<uint64_t>(n, 0x7fffffff);
 }
 
 int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out)

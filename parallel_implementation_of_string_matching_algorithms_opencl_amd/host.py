@@ -62,6 +62,7 @@ SYMBOLS = [
     ("bmx_device_alloc", C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     ("bmx_last_scan_ms", C.c_float, [C.c_void_p]),
     ("bmx_scan_ms_history", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32]),
+    ("bmx_scan_stamps", C.c_int, [C.c_void_p, _u64p, C.c_uint64]),
     ("bmx_scan_geometry", C.c_int, [C.c_void_p, C.c_int32, _u64p]),
     ("bmx_set_variant", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("bmx_gen_text_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]),
@@ -279,6 +280,13 @@ class Context:
             raise BmxError(got, "bmx_scan_ms_history", lib().bmx_last_error().decode(errors="replace"))
         return [float(buf[i]) for i in range(got)]
 
+    def scan_stamps(self, max_words: int = 1 << 16) -> np.ndarray:
+        buf = np.zeros(max_words, dtype=np.uint64)
+        got = lib().bmx_scan_stamps(self._h, buf.ctypes.data_as(_u64p), max_words)
+        if got < 0:
+            raise BmxError(got, "bmx_scan_stamps", lib().bmx_last_error().decode(errors="replace"))
+        return buf[:got].reshape(-1, 8)
+
     def geometry(self, m: int) -> dict:
         g = (C.c_uint64 * 6)()
         _check(lib().bmx_scan_geometry(self._h, m, g), "bmx_scan_geometry")
@@ -318,6 +326,7 @@ class PreparedSearch:
         self._pat = _pat_bytes(pattern)
         n = d_text.numel() if n is None else n
         n_own = n if n_own is None else n_own
+        self.n, self.n_own, self.base_offset, self.tables = n, n_own, base_offset, tables
         gp = bp = None
         if tables is not None:
             self._bad = np.ascontiguousarray(tables[0], dtype=np.int32)

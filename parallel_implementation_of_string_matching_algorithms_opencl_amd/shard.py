@@ -62,6 +62,62 @@ def allgatherv(local, group=None):
     return torch.cat([g[:c] for g, c in zip(gathered, counts_h)]), counts_h
 
 
+class SlotExchange:
+    """The exchange step of a sharded search: every rank publishes ONE fixed-size slot
+    ``[count | offset_0 ... offset_{slot-1}]`` (no host round trip for the counts), one
+    all-gather moves the slots, ``bmx_merge_gathered_device`` compacts them into the
+    global ascending list on every rank.  A result denser than ``slot`` matches on some
+    rank falls back to the exact two-phase :func:`allgatherv`.
+
+    ``via_host=True`` stages the collective through host memory (gloo) -- used by the
+    tests, which run several ranks on ONE GPU where RCCL refuses duplicate devices.
+    """
+
+    def __init__(self, ctx, world: int, rank: int, device, slot: int = 8192, group=None, via_host: bool = False):
+        import torch
+
+        self.ctx, self.world, self.rank, self.slot, self.group, self.via_host = ctx, world, rank, slot, group, via_host
+        self.buf = torch.zeros(slot + 1, dtype=torch.int64, device=device)
+        self.out = self.buf[1:]  # the search writes its ascending offsets here
+        self.gathered = torch.zeros(world * (slot + 1), dtype=torch.int64, device=device)
+        self.merged = torch.zeros(world * slot, dtype=torch.int64, device=device)
+        self.totals = torch.zeros(2, dtype=torch.int64, device=device)
+        self.last_counts = None
+
+    def run(self, query):
+        """query: host.PreparedSearch bound to ``self.out``.  Returns the global list (device tensor)."""
+        import torch
+        import torch.distributed as dist
+
+        query.enqueue()
+        self.ctx.count_to_device(self.buf)
+        if self.via_host:
+            h = self.buf.cpu()
+            hg = torch.empty(self.world * (self.slot + 1), dtype=torch.int64)
+            dist.all_gather_into_tensor(hg, h, group=self.group)
+            self.gathered.copy_(hg)
+        else:
+            dist.all_gather_into_tensor(self.gathered, self.buf, group=self.group)
+        self.ctx.merge_gathered(self.gathered, self.world, self.slot + 1, self.merged, self.totals)
+        local_total = query.finish()
+        total, largest = (int(x) for x in self.totals.cpu())  # the step's one stream synchronisation
+        if largest > self.slot:  # dense result somewhere: exact exchange (every rank takes this branch)
+            full = torch.empty(max(local_total, 1), dtype=torch.int64, device=self.buf.device)
+            exact = self.ctx.prepare(query.d_text, query._pat, full, n=query.n, n_own=query.n_own,
+                                     base_offset=query.base_offset, tables=query.tables)
+            exact.enqueue()
+            got = exact.finish()
+            local = full[:got]
+            if self.via_host:
+                glob, counts = allgatherv(local.cpu(), self.group)
+                glob = glob.to(self.buf.device)
+            else:
+                glob, counts = allgatherv(local, self.group)
+            self.last_counts = counts
+            return glob
+        return self.merged[:total]
+
+
 def merge_shard_lists(lists: List[np.ndarray]) -> np.ndarray:
     """Rank-order concatenation (what allgatherv produces), for single-process checks."""
     if not lists:

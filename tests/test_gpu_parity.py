@@ -14,7 +14,7 @@ from parallel_implementation_of_string_matching_algorithms_opencl_amd import cor
 
 pytestmark = pytest.mark.gpu
 
-N_VARIANTS = 9  # bmx_shim.hip: variants 0..8 are products, the rest timing experiments
+N_VARIANTS = 12  # bmx_shim.hip: variants 0..11 are products, the rest timing experiments
 
 
 def sha(a):

@@ -1,0 +1,94 @@
+"""GPU suite, N > 1 path: several ranks (one process each, as bench.py runs them)
+scan their shards with the HIP kernel and exchange match offsets through
+shard.SlotExchange.  The ranks share the ONE GPU of the test box, where RCCL
+refuses duplicate devices, so the collective is staged through host memory on
+gloo (via_host=True); everything else -- shard extents, halo, ownership,
+global offsets, [count|offsets] slots, bmx_merge_gathered_device, the dense
+fallback -- is the code bench.py runs on 2/4/8 GPUs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, spec_args, slot, q):
+    import torch
+    import torch.distributed as dist
+
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus, host, shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        spec = corpus.CorpusSpec(*spec_args)
+        ctx = host.Context(0)
+        start, length, n_own = shard.shard_extent(spec.n, spec.m, world, rank)
+        d_text = spec.device_text(ctx, start, length, device=dev)
+        xchg = shard.SlotExchange(ctx, world, rank, dev, slot=slot, via_host=True)
+        query = ctx.prepare(d_text, spec.pattern(), xchg.out, n=length, n_own=n_own, base_offset=start,
+                            tables=host.build_tables(spec.pattern()))
+        res = None
+        for _ in range(3):  # repeated steps reuse the slots and re-arm the counters
+            res = xchg.run(query)
+        got = res.cpu().numpy().astype(np.uint64)
+        if rank == 0:
+            q.put(got)
+        dist.barrier()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, spec_args, slot):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, spec_args, slot, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_scan_with_slot_exchange(world, port, ctx):
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus
+
+    n = 24 * (1 << 20) + 1234
+    spec_args = ("sharded", n, 16, 0, 0x5EED0004, 1 << 18, 1 << 22, -1)
+    spec = corpus.CorpusSpec(*spec_args)
+    want = port.search(spec.host_text(), spec.pattern())
+    assert np.array_equal(want, spec.planted_offsets())
+    got = _run(world, spec_args, slot=8192)
+    assert np.array_equal(got, want)
+
+
+def test_sharded_scan_dense_result_takes_exact_exchange(port, ctx):
+    """More matches per shard than a slot holds: every rank must fall back to the
+    counts + padded all-gather and still produce the global ascending list."""
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus
+
+    # ACGT text, 5-byte pattern taken from the text: thousands of natural matches
+    spec_args = ("dense", 3 * (1 << 20) + 77, 5, 1, 0x5EED0031, 0, 0, 4321)
+    spec = corpus.CorpusSpec(*spec_args)
+    want = port.search(spec.host_text(), spec.pattern())
+    assert want.size > 2 * 256
+    got = _run(2, spec_args, slot=256)
+    assert np.array_equal(got, want)
