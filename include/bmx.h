@@ -159,6 +159,23 @@ int bmx_scan_stamps(bmx_ctx *ctx, uint64_t *out, uint64_t max_words);
 /* Tuning knob for experiments: 0 = default kernel variant. */
 int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu);
 
+/* ---- edit distance: the reference's second algorithm ------------ */
+
+/* Levenshtein distance between a[0..la) and b[0..lb): replaces the host loop of
+ * EditDistance-1/EditDistance-1/EditDistance-1.cpp:278-345 (one launch of kernal.cl:5-56
+ * per anti-diagonal over a full (la+1) x (lb+1) table) and its CPU twin
+ * sequential.c:18-46 (editDistDP).  Only the distance is returned -- the value the
+ * reference prints (EditDistance-1.cpp:369); the table is never materialised.
+ * Any lengths < 2^31 (the reference is only correct for equal lengths). */
+int bmx_edit_distance(bmx_ctx *ctx, const char *a, uint64_t la, const char *b, uint64_t lb,
+                      uint64_t *distance);
+int bmx_edit_distance_device(bmx_ctx *ctx, const void *d_a, uint64_t la, const void *d_b, uint64_t lb,
+                             uint64_t *distance, void *stream);
+/* Device time (ms, HIP events around all tile-diagonal launches) of the last call. */
+float bmx_last_edit_distance_ms(bmx_ctx *ctx);
+/* Tile shape for experiments: 0 = default (256 x 256 cells per wave). */
+int bmx_set_ed_variant(bmx_ctx *ctx, int variant);
+
 /* ---- synthetic corpus, generated in HBM ---------------------- */
 
 /* d_dst[j] = byte (start + j) of the counter-based splitmix64 stream;

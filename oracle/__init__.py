@@ -121,6 +121,8 @@ class Port(_Checker):
         L.bmo_gen_text.restype = None
         L.bmo_splitmix64.argtypes = [C.c_uint64]
         L.bmo_splitmix64.restype = C.c_uint64
+        L.edo_edit_distance.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.edo_edit_distance.restype = C.c_int64
         self.lib = L
         self._build = L.bmo_build_tables
         self._scan = L.bmo_scan
@@ -149,6 +151,15 @@ class Port(_Checker):
             raise ValueError(f"bmo_scan_ranges rc={rc}")
         return ans[:P].copy()
 
+    def edit_distance(self, a, b) -> int:
+        """Levenshtein distance, two-row restatement of the reference's editDistDP."""
+        pa, la, ka = _text_ptr(a)
+        pb, lb, kb = _text_ptr(b)
+        d = int(self.lib.edo_edit_distance(pa, la, pb, lb))
+        if d < 0:
+            raise MemoryError("edo_edit_distance")
+        return d
+
     def gen_text(self, start: int, length: int, seed: int, kind: int = 0) -> np.ndarray:
         out = np.empty(length, dtype=np.uint8)
         self.lib.bmo_gen_text(out.ctypes.data_as(C.c_void_p), start, length, seed & (2**64 - 1), kind)
@@ -168,10 +179,21 @@ class Reference(_Checker):
         L.bmref_scan_ranges.argtypes = [C.c_void_p, _u8p, _i32p, C.c_int32, _i32p, _i32p, _i32p, C.c_int32,
                                         _u64p, C.c_uint64, _u64p]
         L.bmref_scan_ranges.restype = C.c_int
+        L.bmref_edit_distance.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.bmref_edit_distance.restype = C.c_int64
         self.lib = L
         self._build = L.bmref_build_tables
         # the reference kernel takes (gstable, bstable) in that order; keep one calling shape
         self._scan = lambda t, n, p, m, bad, good, out, cap: L.bmref_scan(t, n, p, m, bad, good, out, cap)
+
+    def edit_distance(self, a, b) -> int:
+        """The reference's own editDistDP (sequential.c:18-46); full table, <= 20000 chars."""
+        pa, la, ka = _text_ptr(a)
+        pb, lb, kb = _text_ptr(b)
+        d = int(self.lib.bmref_edit_distance(pa, la, pb, lb))
+        if d < 0:
+            raise ValueError("reference editDistDP: strings too long for its full table")
+        return d
 
     def scan_ranges(self, text, pattern, ranges):
         """Per-range counts and the hit offsets in kernel call order."""

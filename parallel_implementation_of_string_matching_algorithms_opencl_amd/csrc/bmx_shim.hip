@@ -18,6 +18,7 @@
 #include "bmx_scan_kernel.h"
 
 #include "bmx_aux_kernels.h"
+#include "bmx_ed_kernel.h"
 #include "bmx_scan_ring_kernel.h"
 #include "bmx_scan_wave_kernel.h"
 
@@ -106,6 +107,8 @@ struct bmx_ctx {
     int num_cu = 256;
     int variant = 0;
     bool auto_walker = true; // until bmx_set_variant(): variant 0 or 1 by the pattern's alphabet
+    int ed_variant = 0;      // edit-distance tile shape (bmx_set_ed_variant)
+    float ed_last_ms = -1.0f;
     int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
     unsigned long long *d_count = nullptr; // live match counter; re-armed by order_kernel
     uint32_t *d_bucket_cnt = nullptr;      // ORDER_BUCKETS, re-armed by order_kernel
@@ -488,6 +491,106 @@ int bmx_scan_stamps(bmx_ctx *ctx, uint64_t *out, uint64_t max_words)
     const uint64_t n = std::min(max_words, ctx->stamp_words);
     if (n) HIPCHK(hipMemcpy(out, ctx->d_stamps, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return (int)std::min<uint64_t>(n, 0x7fffffff);
+}
+
+// ---- edit distance ---------------------------------------------------
+namespace {
+struct EdVariant {
+    int c, r;
+    void (*kernel)(const bmx::EdArgs);
+};
+#define BMX_ED(C_, R_) {C_, R_, bmx::ed_tile_kernel<C_, R_>}
+const EdVariant g_ed_variants[] = {
+    BMX_ED(4, 256), // 0: default: 256 x 256 tiles
+    BMX_ED(2, 256), // 1
+    BMX_ED(8, 256), // 2
+    BMX_ED(4, 512), // 3
+    BMX_ED(2, 128), // 4
+    BMX_ED(1, 128), // 5
+};
+constexpr int N_ED_VARIANTS = sizeof(g_ed_variants) / sizeof(g_ed_variants[0]);
+} // namespace
+
+int bmx_set_ed_variant(bmx_ctx *ctx, int variant)
+{
+    if (!ctx || variant < 0 || variant >= N_ED_VARIANTS) return BMX_ERR_ARG;
+    ctx->ed_variant = variant;
+    return BMX_OK;
+}
+
+float bmx_last_edit_distance_ms(bmx_ctx *ctx) { return ctx ? ctx->ed_last_ms : -1.0f; }
+
+int bmx_edit_distance_device(bmx_ctx *ctx, const void *d_a, uint64_t la, const void *d_b, uint64_t lb,
+                             uint64_t *distance, void *stream_v)
+{
+    if (!ctx || !distance || (la > 0 && !d_a) || (lb > 0 && !d_b)) return BMX_ERR_ARG;
+    if (la >= (1ull << 31) || lb >= (1ull << 31)) return BMX_ERR_ARG;
+    ctx->ed_last_ms = -1.0f;
+    if (la == 0 || lb == 0) { // D[0][c] = c, D[r][0] = r (sequential.c:28-32)
+        *distance = la + lb;
+        return BMX_OK;
+    }
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIPCHK(hipSetDevice(ctx->device));
+    const EdVariant &v = g_ed_variants[ctx->ed_variant];
+    const uint32_t W = 64u * v.c, R = (uint32_t)v.r;
+    bmx::EdArgs a;
+    a.a = (const uint8_t *)d_a;
+    a.b = (const uint8_t *)d_b;
+    a.la = (uint32_t)la;
+    a.lb = (uint32_t)lb;
+    a.tile_cols = (a.la + W - 1) / W;
+    a.tile_rows = (a.lb + R - 1) / R;
+    uint32_t *ws = nullptr; // [3 x (la+1) bottom rows | lb+1 right column | result]
+    const uint64_t words = 3 * (la + 1) + (lb + 1) + 1;
+    HIPCHK(hipMalloc(&ws, words * sizeof(uint32_t)));
+    a.bottom = ws;
+    a.rightcol = ws + 3 * (la + 1);
+    a.result = a.rightcol + (lb + 1);
+    const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING); // borrow an event pair, outside the scan history
+    hipError_t e = hipEventRecord(ctx->ev0[slot], stream);
+    const uint32_t ndiag = a.tile_rows + a.tile_cols - 1;
+    for (uint32_t d = 0; d < ndiag && e == hipSuccess; ++d) {
+        const uint32_t i_lo = d >= a.tile_cols ? d - (a.tile_cols - 1) : 0;
+        const uint32_t i_hi = std::min(d, a.tile_rows - 1);
+        a.diag = d;
+        hipLaunchKernelGGL(v.kernel, dim3(i_hi - i_lo + 1), dim3(64), 0, stream, a);
+        e = hipGetLastError();
+    }
+    uint32_t h_result = 0;
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1[slot], stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_result, a.result, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) (void)hipEventElapsedTime(&ctx->ed_last_ms, ctx->ev0[slot], ctx->ev1[slot]);
+    (void)hipFree(ws);
+    if (e != hipSuccess) {
+        set_err("bmx_edit_distance_device: %s", hipGetErrorString(e));
+        return BMX_ERR_HIP;
+    }
+    *distance = h_result;
+    return BMX_OK;
+}
+
+int bmx_edit_distance(bmx_ctx *ctx_in, const char *a, uint64_t la, const char *b, uint64_t lb, uint64_t *distance)
+{
+    if (!distance || (la > 0 && !a) || (lb > 0 && !b)) return BMX_ERR_ARG;
+    if (la == 0 || lb == 0) {
+        *distance = la + lb;
+        return BMX_OK;
+    }
+    bmx_ctx *ctx = ctx_in;
+    if (!ctx) {
+        int rc = bmx_ctx_create(0, &ctx);
+        if (rc != BMX_OK) return rc;
+    }
+    void *d_a = nullptr, *d_b = nullptr;
+    int rc = bmx_text_upload(ctx, a, la, &d_a);
+    if (rc == BMX_OK) rc = bmx_text_upload(ctx, b, lb, &d_b);
+    if (rc == BMX_OK) rc = bmx_edit_distance_device(ctx, d_a, la, d_b, lb, distance, nullptr);
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (!ctx_in) bmx_ctx_destroy(ctx);
+    return rc;
 }
 
 int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out)

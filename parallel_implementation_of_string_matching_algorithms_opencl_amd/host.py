@@ -65,6 +65,11 @@ SYMBOLS = [
     ("bmx_scan_stamps", C.c_int, [C.c_void_p, _u64p, C.c_uint64]),
     ("bmx_scan_geometry", C.c_int, [C.c_void_p, C.c_int32, _u64p]),
     ("bmx_set_variant", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("bmx_edit_distance", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]),
+    ("bmx_edit_distance_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
+                                           C.c_void_p]),
+    ("bmx_last_edit_distance_ms", C.c_float, [C.c_void_p]),
+    ("bmx_set_ed_variant", C.c_int, [C.c_void_p, C.c_int]),
     ("bmx_gen_text_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]),
     ("bmx_plant_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int32, _u64p,
                                    C.c_uint64, C.c_void_p]),
@@ -295,6 +300,32 @@ class Context:
 
     def set_variant(self, variant: int, blocks_per_cu: int = 0):
         _check(lib().bmx_set_variant(self._h, variant, blocks_per_cu), "bmx_set_variant")
+
+    # -- edit distance (the reference's second algorithm) --------------------
+    def edit_distance(self, a, b) -> int:
+        """Levenshtein distance of two host strings (EditDistance-1.cpp's contract: the
+        last cell of the table)."""
+        pa, la, ka = _host_text(a)
+        pb, lb, kb = _host_text(b)
+        d = C.c_uint64(0)
+        _check(lib().bmx_edit_distance(self._h, pa, la, pb, lb, C.byref(d)), "bmx_edit_distance")
+        return int(d.value)
+
+    def edit_distance_device(self, d_a, d_b) -> int:
+        import torch
+
+        stream = C.c_void_p(torch.cuda.current_stream(d_a.device).cuda_stream)
+        d = C.c_uint64(0)
+        _check(lib().bmx_edit_distance_device(self._h, C.c_void_p(d_a.data_ptr()), d_a.numel(),
+                                              C.c_void_p(d_b.data_ptr()), d_b.numel(), C.byref(d), stream),
+               "bmx_edit_distance_device")
+        return int(d.value)
+
+    def last_edit_distance_ms(self) -> float:
+        return float(lib().bmx_last_edit_distance_ms(self._h))
+
+    def set_ed_variant(self, v: int):
+        _check(lib().bmx_set_ed_variant(self._h, v), "bmx_set_ed_variant")
 
     # -- synthetic corpus in HBM ------------------------------------------
     def gen_text(self, d_dst, start: int, seed: int, kind: int = 0, length: Optional[int] = None):

@@ -148,6 +148,31 @@ def main():
             ranges.append({"file": "input7.txt", "pattern": p, "se": se, "ans": ans.tolist(), "hits": hits.tolist()})
     json.dump({"source": "oracle/_ref: kernel1.cl run for work-items 0..P-1 as BoyreMoore.cpp:264-286 launches it",
                "cases": ranges}, open(os.path.join(HERE, "ranges.json"), "w"))
+    # ---- 6. edit distance (second algorithm): reference editDistDP, sequential.c:18-46 ----
+    ed_dir = "EditDistance-1/EditDistance-1/"
+    ed = []
+    for name, fa, fb, n in [("ED-1", "str1_14k.txt", "str2.txt", 3000), ("ED-2", "str1_0.txt", "str2.txt", 6000),
+                            ("ED-3", "str1_3.txt", "str2.txt", 1000), ("ED-4", "str1.txt", "str1_5.txt", 2500)]:
+        xa = open(os.path.join(REF_ROOT, ed_dir, fa), "rb").read()[:n]
+        xb = open(os.path.join(REF_ROOT, ed_dir, fb), "rb").read()[:n]
+        for tag, raw in (("a", xa), ("b", xb)):
+            with open(os.path.join(data_dir, f"{name}_{tag}.txt"), "wb") as f:
+                f.write(raw)
+        ed.append({"name": name, "a_file": f"{name}_a.txt", "b_file": f"{name}_b.txt",
+                   "reference_files": [ed_dir + fa, ed_dir + fb], "prefix_bytes": n,
+                   "distance": ref.edit_distance(xa, xb)})
+    lits = [("kitten", "sitting"), ("", "abc"), ("abc", ""), ("a", "a"), ("flaw", "lawn"), ("intention", "execution"),
+            ("GATTACA", "GCATGCU"), ("aaaa", "aaaa"), ("abcdef", "azced")]
+    for _ in range(300):
+        alpha = int(rng.integers(1, 5))
+        la, lb = int(rng.integers(0, 400)), int(rng.integers(0, 400))
+        lits.append(("".join(chr(97 + int(c)) for c in rng.integers(0, alpha, la)),
+                     "".join(chr(97 + int(c)) for c in rng.integers(0, alpha, lb))))
+    for xa, xb in lits:
+        ed.append({"a": xa, "b": xb, "distance": ref.edit_distance(xa, xb)})
+    json.dump({"source": "oracle/_ref: the reference's editDistDP (EditDistance-1/EditDistance-1/sequential.c:18-46); "
+                         "ED-1 / ED-2 are SURVEY.md s4's known answers (522, 1044)", "cases": ed},
+              open(os.path.join(HERE, "edit_distance.json"), "w"))
     print("golden fixtures written:", sorted(os.listdir(HERE)))
 
 

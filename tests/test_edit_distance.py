@@ -1,0 +1,126 @@
+"""Edit distance (the reference's second algorithm, SURVEY.md s8 f1 / BASELINE config 5).
+
+CPU part: the two-row oracle (oracle/ed_oracle.c) against golden distances produced by
+the reference's own editDistDP (tests/golden/edit_distance.json) and against the
+reference build.  GPU part: bmx_edit_distance through the C ABI against the same
+fixtures, the oracle on seeded inputs around the tile edges, and size-independent
+properties at 64k x 64k."""
+import numpy as np
+import pytest
+
+from conftest import golden_file_bytes, load_golden
+
+
+def _case_strings(case):
+    if "a_file" in case:
+        return golden_file_bytes(case["a_file"]), golden_file_bytes(case["b_file"])
+    return case["a"].encode("latin-1"), case["b"].encode("latin-1")
+
+
+# ------------------------------------------------------------------ CPU (oracle)
+def test_oracle_matches_reference_editDistDP_golden(port):
+    for case in load_golden("edit_distance.json"):
+        a, b = _case_strings(case)
+        assert port.edit_distance(a, b) == case["distance"], case.get("name", (case.get("a"), case.get("b")))
+
+
+def test_survey_known_answers(port):
+    cases = {c["name"]: c for c in load_golden("edit_distance.json") if "name" in c}
+    assert cases["ED-1"]["distance"] == 522 and cases["ED-2"]["distance"] == 1044
+    assert cases["ED-1"]["prefix_bytes"] == 3000 and cases["ED-2"]["prefix_bytes"] == 6000
+
+
+def test_oracle_equals_reference_build_random(port, reference):
+    if reference is None:
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(42)
+    for _ in range(200):
+        la, lb = int(rng.integers(0, 700)), int(rng.integers(0, 700))
+        al = int(rng.integers(1, 6))
+        x = (rng.integers(0, al, la) + 97).astype(np.uint8)
+        y = (rng.integers(0, al, lb) + 97).astype(np.uint8)
+        assert port.edit_distance(x, y) == reference.edit_distance(x, y)
+
+
+def test_oracle_metric_properties(port):
+    rng = np.random.default_rng(1)
+    for _ in range(30):
+        x = (rng.integers(0, 4, int(rng.integers(1, 300))) + 65).astype(np.uint8)
+        y = (rng.integers(0, 4, int(rng.integers(1, 300))) + 65).astype(np.uint8)
+        d = port.edit_distance(x, y)
+        assert d == port.edit_distance(y, x)
+        assert abs(len(x) - len(y)) <= d <= max(len(x), len(y))
+        assert port.edit_distance(x, x) == 0
+
+
+# ------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_golden(ctx):
+    for case in load_golden("edit_distance.json"):
+        a, b = _case_strings(case)
+        assert ctx.edit_distance(a, b) == case["distance"], case.get("name", (case.get("a"), case.get("b")))
+
+
+@pytest.mark.gpu
+def test_gpu_vs_oracle_around_tile_edges_all_tile_shapes(ctx, port):
+    """Lengths straddling the tile width/height (64*C columns, R rows) of every tile shape,
+    unequal lengths included (the reference itself is only right for equal lengths)."""
+    rng = np.random.default_rng(7)
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 1025]
+    try:
+        for v in range(6):
+            ctx.set_ed_variant(v)
+            for _ in range(14):
+                la, lb = int(rng.choice(lens)), int(rng.choice(lens))
+                al = int(rng.integers(2, 5))
+                x = (rng.integers(0, al, la) + 97).astype(np.uint8)
+                y = (rng.integers(0, al, lb) + 97).astype(np.uint8)
+                assert ctx.edit_distance(x, y) == port.edit_distance(x, y), (v, la, lb)
+    finally:
+        ctx.set_ed_variant(0)
+
+
+@pytest.mark.gpu
+def test_gpu_degenerate(ctx):
+    assert ctx.edit_distance(b"", b"") == 0
+    assert ctx.edit_distance(b"", b"abc") == 3
+    assert ctx.edit_distance(b"abcd", b"") == 4
+    assert ctx.edit_distance(b"kitten", b"sitting") == 3
+    assert ctx.edit_distance(b"a" * 3000, b"a" * 3000) == 0
+    assert ctx.edit_distance(b"a" * 3000, b"b" * 2000) == 3000
+
+
+@pytest.mark.gpu
+def test_gpu_mid_size_vs_oracle(ctx, port):
+    rng = np.random.default_rng(3)
+    x = (rng.integers(0, 4, 9000) + 65).astype(np.uint8)
+    y = x.copy()
+    y[rng.integers(0, 9000, 700)] = ord("N")       # substitutions
+    y = np.delete(y, rng.integers(0, 9000, 200))   # deletions
+    assert ctx.edit_distance(x, y) == port.edit_distance(x, y)
+    z = (rng.integers(0, 4, 7777) + 65).astype(np.uint8)
+    assert ctx.edit_distance(x, z) == port.edit_distance(x, z)
+
+
+@pytest.mark.gpu
+def test_gpu_config5_64k_properties(ctx, port):
+    """BASELINE config 5: 64k x 64k.  Known-by-construction answers plus one full
+    comparison with the two-row oracle (13 s of CPU)."""
+    import torch
+
+    n = 65536
+    rng = np.random.default_rng(5)
+    x = (rng.integers(0, 4, n) + 65).astype(np.uint8)
+    dx = torch.from_numpy(x).cuda()
+    assert ctx.edit_distance_device(dx, dx) == 0
+    # k substitutions at distinct positions with a fifth symbol: distance is exactly k
+    y = x.copy()
+    pos = rng.choice(n, 1000, replace=False)
+    y[pos] = ord("N")
+    assert ctx.edit_distance_device(dx, torch.from_numpy(y).cuda()) == 1000
+    # symmetry on unrelated strings, then the oracle
+    z = (rng.integers(0, 4, n) + 65).astype(np.uint8)
+    dz = torch.from_numpy(z).cuda()
+    d1 = ctx.edit_distance_device(dx, dz)
+    assert d1 == ctx.edit_distance_device(dz, dx)
+    assert d1 == port.edit_distance(x, z)
