@@ -89,13 +89,54 @@ def cpu_baseline(h_text: np.ndarray, pat: bytes, gpu_list: np.ndarray, budget_s:
     }, ok
 
 
+def bench_edit_distance(args, dev, local_rank):
+    """Config 5: Levenshtein distance of two 64k-character ACGT strings on one GPU.  A step is
+    one distance computation with both strings resident; cell updates per second."""
+    n = 65536
+    rng = np.random.default_rng(0x5EED0005)
+    x = (rng.integers(0, 4, n) + 65).astype(np.uint8)
+    z = (rng.integers(0, 4, n) + 65).astype(np.uint8)
+    ctx = host.Context(local_rank)
+    dx, dz = torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev)
+    for _ in range(args.warmup):
+        d = ctx.edit_distance_device(dx, dz)
+    torch.cuda.synchronize()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d = ctx.edit_distance_device(dx, dz)
+        kern_ms.append(ctx.last_edit_distance_ms())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    line = {"metric": "edit-distance cell updates, 64k x 64k chars, 1x MI355X (BASELINE config 5)",
+            "value": round(n * n * args.steps / elapsed / 1e9, 2), "unit": "GCUPS", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "ed64k", "rows": n, "cols": n, "alphabet": "ACGT", "distance": int(d),
+                       "device_ms": round(float(np.mean(kern_ms)), 3)},
+            "roofline": None}
+    if not args.no_cpu_baseline:
+        import oracle  # reported baseline + checker only
+
+        t0 = time.perf_counter()
+        want = oracle.port().edit_distance(x, z)
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(n * n / dt / 1e9, 3), "unit": "GCUPS", "cores": 1, "kind": "port",
+                                "sample": f"one full 64k x 64k pass of the two-row restatement, {dt:.1f} s"}
+        line["parity"] = {"distance_equals_cpu_oracle": bool(want == d)}
+    print(json.dumps(line), flush=True)
+    ctx.close()
+    if "parity" in line and not line["parity"]["distance_equals_cpu_oracle"]:
+        sys.exit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gib-per-gpu", type=float, default=4.0)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg3b"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg3b", "ed64k"])
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
@@ -114,6 +155,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload == "ed64k":  # BASELINE config 5 (secondary: the reference's second algorithm)
+        return bench_edit_distance(args, dev, local_rank)
 
     per_gpu = int(args.gib_per_gpu * (1 << 30))
     base = {"cfg2": corpus.CONFIGS["cfg2_4GiB_m16"], "cfg3": corpus.CONFIGS["cfg3_4GiB_m64_acgt"],

@@ -150,7 +150,7 @@ int bmx_scan_ms_history(bmx_ctx *ctx, float *ms_out, int32_t max_n);
 /* Scan-kernel launch geometry for pattern length m: out[0]=grid (workgroups),
  * out[1]=threads per workgroup, out[2]=window starts per synchronisation unit
  * (workgroup tile or wave piece), out[3]=LDS bytes per workgroup, out[4]=window
- * starts per lane, out[5]=kernel kind (0 workgroup tiles, 1 wave streams). */
+ * starts per lane, out[5]=kernel kind (0 workgroup tiles, 1 wave streams, 2 three-buffer ring). */
 int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6]);
 /* Diagnostic kernel builds only (variant 15): per-wave s_memtime sums of the last
  * launch, 8 words per wave {issue, walk, dma_wait, barrier_wait, tiles, 0, 0, 0}.

@@ -296,7 +296,7 @@ class Context:
         g = (C.c_uint64 * 6)()
         _check(lib().bmx_scan_geometry(self._h, m, g), "bmx_scan_geometry")
         return {"grid": int(g[0]), "block": int(g[1]), "tile_bytes": int(g[2]), "lds_bytes": int(g[3]),
-                "seg": int(g[4]), "kind": "wave-stream" if g[5] else "workgroup-tile"}
+                "seg": int(g[4]), "kind": ("workgroup-tile", "wave-stream", "workgroup-ring")[int(g[5])]}
 
     def set_variant(self, variant: int, blocks_per_cu: int = 0):
         _check(lib().bmx_set_variant(self._h, variant, blocks_per_cu), "bmx_set_variant")
