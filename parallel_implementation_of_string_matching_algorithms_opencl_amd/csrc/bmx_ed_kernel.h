@@ -20,18 +20,21 @@
 //    step; up and diagonal values never leave the lane's registers.
 //  * Integer min/add only; no MFMA (a DP recurrence is not a contraction).
 //
-// Measured (MI355X, 64k x 64k): 25 ms = 168 GCUPS with 256 x 256 tiles; rocprofv3 shows
-// ~50 us per launch = ~330 cycles per step for ~60 instructions: ONE wave per CU issues
-// an instruction every ~5 cycles, and the chain of 511 dependent tile diagonals is the
-// critical path (wavefront parallelism is min(TR, TC) <= 256 waves on 1024 SIMDs).  A
-// variant that replaced the shuffle by DPP wave_shr:1 and kept the tile boundaries in
-// registers (v_readlane by step index) removed all LDS traffic from the loop but not
-// instructions, and was 8 % slower; per-step instruction count is the lever for a later
-// round.
+// Measured (MI355X, 64k x 64k): 23-25 ms = 170-185 GCUPS; rocprofv3 shows ~50 us per
+// 256 x 256 tile launch = ~320 cycles per step: the ONE wave of a CU issues an instruction
+// every ~6 cycles whether dependent or not, and the chain of dependent tile diagonals is
+// the critical path (at most 256 of 1024 SIMDs are busy).  The lean step (52 instead of
+// ~70 instructions) gained 3 %, fetching the row character one step ahead LOST 12 % (its
+// index clamp costs more instructions than the LDS latency it hides): instruction count
+// per step is the only lever inside this schedule; the next one is the schedule itself
+// (persistent workgroups with 64-row hand-offs instead of one launch per tile diagonal:
+// 98k instead of 163k steps on the critical path).
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 namespace bmx {
 
@@ -46,7 +49,14 @@ struct EdArgs {
     uint32_t diag;                 // tile anti-diagonal of this launch
 };
 
-template <int C, int R>
+// LEAN = false: the first version (shuffle through ds_bpermute, every step predicated).
+// LEAN = true: fewer instructions per step -- the tile's steps are split into ramp-up,
+// steady state (every lane inside the tile: no predication at all) and ramp-down; the
+// left neighbour's value moves by one DPP wave_shr:1, lane 0's boundary value comes out
+// of a register by v_readlane; the cell update is min3(left, up, diag - 1 + ne) + 1,
+// which equals the reference's "equal ? diag : 1 + min3" on every valid table because
+// neighbouring cells differ by at most 1 (so diag <= left + 1 and diag <= up + 1).
+template <int C, int R, bool LEAN = false>
 __global__ __launch_bounds__(64) void ed_tile_kernel(const EdArgs a)
 {
     constexpr uint32_t W = 64 * C;
@@ -91,37 +101,91 @@ __global__ __launch_bounds__(64) void ed_tile_kernel(const EdArgs a)
     }
     __syncthreads();
 
+    if (LEAN) {
+        uint32_t last = 0;                     // my right-most value of the previous step
+        uint32_t blk_left = 0, blk_right = 0;  // 64 rows' worth of boundary values, one per lane
+        auto step = [&](uint32_t s, auto check_tag) {
+            constexpr bool CHECK = decltype(check_tag)::value;
+            const uint32_t j = s & 63;
+            if (j == 0) { // lane 0 enters a new block of 64 rows (wave-uniform branch)
+                const uint32_t r = s + lane;
+                blk_left = r < rows ? s_left[r] : 0;
+            }
+            const uint32_t left0 = __builtin_amdgcn_readlane(blk_left, j); // lane 0's left input
+            uint32_t left = __builtin_amdgcn_update_dpp(left0, last, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+            const int32_t rr = (int32_t)s - (int32_t)lane;
+            const bool active = !CHECK || (rr >= 0 && rr < (int32_t)rows);
+            const uint32_t bc = s_b[CHECK ? (active ? (uint32_t)rr : 0u) : (uint32_t)rr];
+            uint32_t diag = diag_in;
+            const uint32_t left_in = left;
+            uint32_t v = 0;
+            uint32_t Hn[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const uint32_t up = H[k];
+                const int32_t x = (int32_t)diag - 1 + (bc != ac[k] ? 1 : 0);
+                int32_t mi = (int32_t)left < (int32_t)up ? (int32_t)left : (int32_t)up;
+                mi = mi < x ? mi : x;
+                v = (uint32_t)(mi + 1); // = bc == ac[k] ? diag : 1 + min3 (kernal.cl:34-53) on a valid table
+                diag = up;
+                left = v;
+                Hn[k] = v;
+            }
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < C; ++k) H[k] = Hn[k];
+                diag_in = left_in;
+                last = v;
+            }
+            if (s >= 63) { // lane 63 is at row s-63: collect its value, flush 64 at a time
+                const uint32_t r63 = s - 63;
+                const uint32_t v63 = __builtin_amdgcn_readlane(last, 63);
+                blk_right = lane == (r63 & 63) ? v63 : blk_right;
+                if ((r63 & 63) == 63 || r63 + 1 == rows) {
+                    const uint32_t r = (r63 & ~63u) + lane;
+                    if (r < rows) s_right[r] = blk_right;
+                }
+            }
+        };
+        const uint32_t steps = rows + 63;
+        const uint32_t ramp = steps < 63 ? steps : 63;
+        uint32_t s = 0;
+        for (; s < ramp; ++s) step(s, std::true_type{});
+        for (; s < rows; ++s) step(s, std::false_type{}); // 63 <= s < rows: all 64 lanes inside the tile
+        for (; s < steps; ++s) step(s, std::true_type{});
+    } else {
     uint32_t last = 0; // my right-most value of the previous step (what lane+1 reads)
-    const uint32_t steps = rows + 63;
-    for (uint32_t s = 0; s < steps; ++s) {
-        const uint32_t from_left = __shfl_up(last, 1); // lane l-1's right-most value of step s-1 = D[my row][c_first-1]
-        const int32_t rr = (int32_t)s - (int32_t)lane;
-        const bool active = rr >= 0 && rr < (int32_t)rows;
-        const uint32_t rri = active ? (uint32_t)rr : 0u;
-        uint32_t left = lane == 0 ? s_left[rri] : from_left;
-        const uint32_t bc = s_b[rri];
-        uint32_t diag = diag_in;
-        const uint32_t left_in = left;
-        uint32_t v = 0;
-        uint32_t Hn[C];
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-            const uint32_t up = H[k];
-            uint32_t mi = diag < left ? diag : left; // kernal.cl:46-52
-            mi = mi < up ? mi : up;
-            v = bc == ac[k] ? diag : mi + 1;         // kernal.cl:34-38 / :53
-            diag = up;
-            left = v;
-            Hn[k] = v;
+        const uint32_t steps = rows + 63;
+        for (uint32_t s = 0; s < steps; ++s) {
+            const uint32_t from_left = __shfl_up(last, 1); // lane l-1's right-most value of step s-1 = D[my row][c_first-1]
+            const int32_t rr = (int32_t)s - (int32_t)lane;
+            const bool active = rr >= 0 && rr < (int32_t)rows;
+            const uint32_t rri = active ? (uint32_t)rr : 0u;
+            uint32_t left = lane == 0 ? s_left[rri] : from_left;
+            const uint32_t bc = s_b[rri];
+            uint32_t diag = diag_in;
+            const uint32_t left_in = left;
+            uint32_t v = 0;
+            uint32_t Hn[C];
+    #pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const uint32_t up = H[k];
+                uint32_t mi = diag < left ? diag : left; // kernal.cl:46-52
+                mi = mi < up ? mi : up;
+                v = bc == ac[k] ? diag : mi + 1;         // kernal.cl:34-38 / :53
+                diag = up;
+                left = v;
+                Hn[k] = v;
+            }
+            if (active) {
+    #pragma unroll
+                for (int k = 0; k < C; ++k) H[k] = Hn[k];
+                diag_in = left_in; // next row's diagonal = this row's left input
+                last = v;
+                if (lane == 63) s_right[rri] = v;
+            }
         }
-        if (active) {
-#pragma unroll
-            for (int k = 0; k < C; ++k) H[k] = Hn[k];
-            diag_in = left_in; // next row's diagonal = this row's left input
-            last = v;
-            if (lane == 63) s_right[rri] = v;
-        }
-    }
+}
     __syncthreads();
 
     // boundaries out
