@@ -157,9 +157,12 @@ int blocks_per_cu_for(const bmx_ctx *ctx, const Variant &v, int32_t m)
 // a character of the pattern, shifts are a few bytes and the skip-loop walker is 1.7x
 // faster (2.06 vs 1.2 TB/s on 4 GiB ACGT, m = 64); on wide alphabets the byte-wise walker
 // is ~2 % ahead.  The text is unknown here, the pattern's own alphabet is the hint.
+uint32_t lds_bytes_for(const Variant &v, int32_t m);
+
 int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m)
 {
-    if (!ctx->auto_walker) return ctx->variant;
+    if (!ctx->auto_walker) // an explicitly chosen variant whose buffers + halo do not fit at this m
+        return lds_bytes_for(g_variants[ctx->variant], m) <= LDS_PER_CU ? ctx->variant : 0; // -> default
     if (m < 4) return 0;
     bool seen[256] = {};
     int distinct = 0;

@@ -170,6 +170,21 @@ def test_pattern_lengths_1_99_512(ctx, port):
         assert np.array_equal(dev_search(ctx, text, pat), port.search(text, pat)), m
 
 
+def test_variant_that_does_not_fit_lds_falls_back(ctx, port):
+    """Three 52 KiB buffers + three 512-byte halos exceed the CU's 160 KiB of LDS: an explicitly
+    chosen variant that cannot hold the pattern's halo must fall back to the default kernel."""
+    rng = np.random.default_rng(12)
+    text = (rng.integers(0, 3, 300000) + 97).astype(np.uint8)
+    pat = text[777:777 + 512].tobytes()
+    text[200000:200512] = np.frombuffer(pat, dtype=np.uint8)
+    try:
+        for v in (9, 10, 7):
+            ctx.set_variant(v)
+            assert np.array_equal(dev_search(ctx, text, pat), port.search(text, pat)), v
+    finally:
+        ctx.set_variant(0)
+
+
 def test_misaligned_device_pointers(ctx, port):
     """d_text with every alignment 0..15 and base_offset/n_own (shard) semantics."""
     import torch
