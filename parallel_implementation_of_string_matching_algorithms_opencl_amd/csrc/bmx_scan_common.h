@@ -1,0 +1,236 @@
+// bmx_scan_common.h -- what the three scan kernels share: the kernel-argument block, the
+// LDS-DMA primitive, the wave-aggregated hit append, the broadcast of the shift tables
+// into LDS and the per-lane Boyer-Moore walkers.
+//
+// Reference mapping of the walk (BoyreMoore/x64/Debug/kernel1.cl, the working copy):
+//   :15,19   i = start + m - 1; while (i <= end)          -> walk_lane's loop over a lane's segment
+//   :20-22   k = number of characters matched from the right
+//   :24      k == m: report i - (m-1), advance by 1       -> emit_hit
+//   :27-28   d1 = max(bad[text[i]] - k, 1)  (the window's LAST character, not the mismatching one)
+//   :29-33   shift = k == 0 ? d1 : max(d1, good[k])
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bmx {
+
+constexpr int MAX_PATTERN = 512; // == BMX_MAX_PATTERN
+constexpr int ORDER_BUCKETS = 8192;
+constexpr int ORDER_BUCKET_CAP = 8;
+
+// Shift tables and pattern travel in the kernel-argument segment (1.8 KiB): no
+// device buffers to keep alive, no copies on the launch path, and every
+// workgroup broadcasts them into LDS from the scalar/constant cache.
+struct ScanTables {
+    uint16_t bad[128];          // shift for the window's last byte, already clamped to >= 1
+    uint16_t good[MAX_PATTERN]; // indexed by matched count k = 1..m-1
+    uint8_t pat[MAX_PATTERN];
+};
+
+struct ScanArgs {
+    const uint8_t *text16;   // caller's pointer rounded down to a multiple of 16
+    uint64_t first;          // aligned coordinate of text byte 0 (0..15)
+    uint64_t own_end;        // one past the last window START to report (aligned coords)
+    uint64_t data_end;       // one past the last valid text byte (aligned coords)
+    uint64_t out_bias;       // reported offset = aligned start + out_bias (mod 2^64)
+    uint64_t tile_begin;     // first tile index holding a window start
+    uint64_t tile_end;       // one past the last
+    uint64_t *out;           // match offsets, unordered append (NULL: count only)
+    uint64_t cap;            // capacity of out
+    unsigned long long *count; // TRUE number of matches (may exceed cap)
+    // Ordering buckets (see order_kernel): bucket b holds the matches whose
+    // shard-local start lies in [b << bucket_shift, (b+1) << bucket_shift).
+    uint32_t *bucket_cnt;    // ORDER_BUCKETS counters
+    uint64_t *bucket_store;  // ORDER_BUCKETS x ORDER_BUCKET_CAP offsets
+    uint32_t *bucket_overflow; // set to 1 when a bucket is full
+    uint32_t bucket_shift;
+    unsigned long long *stamps; // MODE 5 only (diagnostic build): per-wave cycle sums, 8 words per wave
+    uint32_t m;
+    uint32_t halo16;         // (m-1) rounded up to a multiple of 16
+    ScanTables tab;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ lds_void *to_lds(const void *p)
+{
+    // the low 32 bits of a generic pointer into LDS are the LDS byte offset
+    return reinterpret_cast<lds_void *>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p)));
+}
+
+// One wave-instruction = 64 lanes x 16 B = 1 KiB from HBM straight into LDS.
+// `lds_wave_base` must be wave-uniform; lane L's 16 bytes land at base + 16*L.
+template <int AUX>
+__device__ __forceinline__ void dma16(const uint8_t *gsrc_lane, const uint8_t *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((gbl_void *)gsrc_lane, to_lds(lds_wave_base), 16, 0, AUX);
+}
+
+// Wave-aggregated append of one match per ACTIVE lane (called under divergence).
+// `local` is the match's start relative to text byte 0 of this shard, `pos` the
+// offset to report.  Every match goes to the unordered list (always complete up
+// to cap: the fallback for dense results) and to its position bucket, from which
+// order_kernel writes the ascending list without a sort.
+__device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint64_t pos)
+{
+    const uint64_t active = __ballot(1);
+    const uint32_t lane = __lane_id();
+    const int leader = __ffsll((unsigned long long)active) - 1;
+    const uint32_t rank = __popcll(active & ((1ull << lane) - 1ull));
+    unsigned long long base = 0;
+    if ((int)lane == leader) base = atomicAdd(a.count, (unsigned long long)__popcll(active));
+    base = __shfl(base, leader);
+    const uint64_t slot = base + rank;
+    if (a.out != nullptr) {
+        if (slot < a.cap) a.out[slot] = pos;
+        const uint32_t b = (uint32_t)(local >> a.bucket_shift);
+        const uint32_t s = atomicAdd(&a.bucket_cnt[b], 1u);
+        if (s < (uint32_t)ORDER_BUCKET_CAP)
+            a.bucket_store[(uint64_t)b * ORDER_BUCKET_CAP + s] = pos;
+        else
+            *a.bucket_overflow = 1u;
+    }
+}
+
+struct LdsTables {
+    const uint16_t *bad;  // 256 x u16 (entry of the pattern's last character: 0 if SKIP)
+    const uint16_t *good; // m x u16
+    const uint8_t *pat;   // m bytes
+    uint32_t m;
+    // scalar copies for the skip-loop walker
+    uint32_t b_last, p3, g1, g2, g3;
+    bool m4;
+};
+
+// One lane walks the window starts [lo, hi) of the tile at T (tile-local indices).
+// SKIP = false: the reference's loop as it stands (kernel1.cl:15-34), one window per
+// round.  SKIP = true: skip loop, two windows per round; the table entry of the
+// pattern's last character is 0, so a window that ends in it stops the walker there;
+// k = 1..3 then comes from three byte reads against scalar registers.
+template <bool SKIP>
+__device__ __forceinline__ void walk_lane(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
+                                          uint32_t hi, uint64_t tile_off)
+{
+    const uint32_t m = tb.m;
+    uint32_t i = lo + m - 1;          // index of the window's last character
+    const uint32_t ilim = hi + m - 1; // exclusive
+    if (!SKIP) {
+        const uint32_t plast = tb.pat[m - 1];
+        while (i < ilim) {
+            const uint32_t c = T[i];
+            const uint32_t b = tb.bad[c];
+            if (c != plast) { // k == 0: shift = max(bad[c] - 0, 1), kernel1.cl:28,30
+                i += b;
+                continue;
+            }
+            uint32_t k = 1; // kernel1.cl:20-22
+            while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+            if (k == m) { // kernel1.cl:24
+                const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
+                emit_hit(a, astart - a.first, astart + a.out_bias);
+                i += 1;
+                continue;
+            }
+            const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28
+            const int d2 = (int)tb.good[k];                             // kernel1.cl:29
+            i += (uint32_t)(d1 > d2 ? d1 : d2);                         // kernel1.cl:31
+        }
+    } else {
+        while (i < ilim) {
+            i += tb.bad[T[i]];
+            const uint32_t b2 = tb.bad[T[i]]; // may look up to m-1 bytes past the segment: never reported
+            i += b2;
+            if (b2 == 0 && i < ilim) {
+                uint32_t k = 1;
+                int d2 = 0;
+                bool have_k = false;
+                if (tb.m4) {
+                    const uint32_t c1 = T[i - 1], c2 = T[i - 2], c3 = T[i - 3];
+                    const uint32_t diff = (c3 | (c2 << 8) | (c1 << 16)) ^ tb.p3;
+                    if (diff != 0) {
+                        k = (uint32_t)__clz((int)diff) >> 3; // top byte is 0: k = 1..3
+                        d2 = k == 1 ? (int)tb.g1 : (k == 2 ? (int)tb.g2 : (int)tb.g3);
+                        have_k = true;
+                    } else {
+                        k = 4;
+                    }
+                }
+                if (!have_k) {
+                    while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+                    if (k == m) {
+                        const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
+                        emit_hit(a, astart - a.first, astart + a.out_bias);
+                        i += 1;
+                        continue;
+                    }
+                    d2 = (int)tb.good[k];
+                }
+                const int d1 = (int)tb.b_last - (int)k > 1 ? (int)tb.b_last - (int)k : 1;
+                i += (uint32_t)(d1 > d2 ? d1 : d2);
+            }
+        }
+    }
+}
+
+// wait until at most n of this wave's vector-memory operations are outstanding
+__device__ __forceinline__ void wait_vmcnt_at_most(uint32_t n)
+{
+    switch (n) { // wave-uniform
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// Broadcast the tables into LDS (layout: 256 x u16 bad | m x u16 good | m bytes pattern, at
+// `base`) and fill the scalar copies the skip-loop walker keeps in registers.  Text bytes
+// >= 0x80 cannot occur in an ASCII pattern: their entry is the full shift m.  The scalars
+// are forced through readfirstlane HERE: a load still pending when the walk first uses it
+// would cost an s_waitcnt vmcnt(0) that also drains the LDS-DMA in flight.
+template <bool SKIP>
+__device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *base, uint32_t tid, uint32_t nthreads)
+{
+    const uint32_t m = a.m;
+    uint16_t *s_bad = reinterpret_cast<uint16_t *>(base);
+    uint16_t *s_good = s_bad + 256;
+    uint8_t *s_pat = reinterpret_cast<uint8_t *>(s_good + ((m + 7) & ~7u));
+    const uint32_t last_char = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 1]);
+    for (uint32_t i = tid; i < 256; i += nthreads) {
+        uint16_t v = i < 128 ? a.tab.bad[i] : (uint16_t)m;
+        if (SKIP && i == last_char) v = 0; // "stop here and compare", the classic skip-loop marker
+        s_bad[i] = v;
+    }
+    for (uint32_t i = tid; i < m; i += nthreads) {
+        s_good[i] = a.tab.good[i];
+        s_pat[i] = a.tab.pat[i];
+    }
+    LdsTables tb;
+    tb.bad = s_bad;
+    tb.good = s_good;
+    tb.pat = s_pat;
+    tb.m = m;
+    tb.m4 = m >= 4;
+    tb.b_last = tb.p3 = tb.g1 = tb.g2 = tb.g3 = 0;
+    if (SKIP) {
+        tb.b_last = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.bad[last_char & 127]);
+        if (tb.m4) {
+            tb.p3 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 4] | ((uint32_t)a.tab.pat[m - 3] << 8) |
+                                                   ((uint32_t)a.tab.pat[m - 2] << 16));
+            tb.g1 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.good[1]);
+            tb.g2 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.good[2]);
+            tb.g3 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.good[3]);
+        }
+    }
+    return tb;
+}
+
+} // namespace bmx

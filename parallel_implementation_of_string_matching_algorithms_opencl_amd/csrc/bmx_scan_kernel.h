@@ -28,89 +28,9 @@
 // hence no read ever touches a 16-B line the caller does not own a byte of.
 #pragma once
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "bmx_scan_common.h"
 
 namespace bmx {
-
-constexpr int MAX_PATTERN = 512; // == BMX_MAX_PATTERN
-constexpr int ORDER_BUCKETS = 8192;
-constexpr int ORDER_BUCKET_CAP = 8;
-
-// Shift tables and pattern travel in the kernel-argument segment (1.8 KiB): no
-// device buffers to keep alive, no copies on the launch path, and every
-// workgroup broadcasts them into LDS from the scalar/constant cache.
-struct ScanTables {
-    uint16_t bad[128];          // shift for the window's last byte, already clamped to >= 1
-    uint16_t good[MAX_PATTERN]; // indexed by matched count k = 1..m-1
-    uint8_t pat[MAX_PATTERN];
-};
-
-struct ScanArgs {
-    const uint8_t *text16;   // caller's pointer rounded down to a multiple of 16
-    uint64_t first;          // aligned coordinate of text byte 0 (0..15)
-    uint64_t own_end;        // one past the last window START to report (aligned coords)
-    uint64_t data_end;       // one past the last valid text byte (aligned coords)
-    uint64_t out_bias;       // reported offset = aligned start + out_bias (mod 2^64)
-    uint64_t tile_begin;     // first tile index holding a window start
-    uint64_t tile_end;       // one past the last
-    uint64_t *out;           // match offsets, unordered append (NULL: count only)
-    uint64_t cap;            // capacity of out
-    unsigned long long *count; // TRUE number of matches (may exceed cap)
-    // Ordering buckets (see order_kernel): bucket b holds the matches whose
-    // shard-local start lies in [b << bucket_shift, (b+1) << bucket_shift).
-    uint32_t *bucket_cnt;    // ORDER_BUCKETS counters
-    uint64_t *bucket_store;  // ORDER_BUCKETS x ORDER_BUCKET_CAP offsets
-    uint32_t *bucket_overflow; // set to 1 when a bucket is full
-    uint32_t bucket_shift;
-    unsigned long long *stamps; // MODE 5 only (diagnostic build): per-wave cycle sums, 8 words per wave
-    uint32_t m;
-    uint32_t halo16;         // (m-1) rounded up to a multiple of 16
-    ScanTables tab;
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
-__device__ __forceinline__ lds_void *to_lds(const void *p)
-{
-    // the low 32 bits of a generic pointer into LDS are the LDS byte offset
-    return reinterpret_cast<lds_void *>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p)));
-}
-
-// One wave-instruction = 64 lanes x 16 B = 1 KiB from HBM straight into LDS.
-// `lds_wave_base` must be wave-uniform; lane L's 16 bytes land at base + 16*L.
-template <int AUX>
-__device__ __forceinline__ void dma16(const uint8_t *gsrc_lane, const uint8_t *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((gbl_void *)gsrc_lane, to_lds(lds_wave_base), 16, 0, AUX);
-}
-
-// Wave-aggregated append of one match per ACTIVE lane (called under divergence).
-// `local` is the match's start relative to text byte 0 of this shard, `pos` the
-// offset to report.  Every match goes to the unordered list (always complete up
-// to cap: the fallback for dense results) and to its position bucket, from which
-// order_kernel writes the ascending list without a sort.
-__device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint64_t pos)
-{
-    const uint64_t active = __ballot(1);
-    const uint32_t lane = __lane_id();
-    const int leader = __ffsll((unsigned long long)active) - 1;
-    const uint32_t rank = __popcll(active & ((1ull << lane) - 1ull));
-    unsigned long long base = 0;
-    if ((int)lane == leader) base = atomicAdd(a.count, (unsigned long long)__popcll(active));
-    base = __shfl(base, leader);
-    const uint64_t slot = base + rank;
-    if (a.out != nullptr) {
-        if (slot < a.cap) a.out[slot] = pos;
-        const uint32_t b = (uint32_t)(local >> a.bucket_shift);
-        const uint32_t s = atomicAdd(&a.bucket_cnt[b], 1u);
-        if (s < (uint32_t)ORDER_BUCKET_CAP)
-            a.bucket_store[(uint64_t)b * ORDER_BUCKET_CAP + s] = pos;
-        else
-            *a.bucket_overflow = 1u;
-    }
-}
 
 // AUX: cache-policy bits of the DMA (0 default, 2 = nt: the text is read once).
 // MODE 0 is the product; MODE 1 (DMA only, no walkers) and MODE 2 (walkers only:
@@ -139,41 +59,13 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
     const ScanArgs &a = a_in;
     extern __shared__ uint4 smem_u4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(smem_u4);
-    const uint32_t m = a.m;
     const uint32_t buf_bytes = TILE + a.halo16; // multiple of 16
     uint8_t *buf0 = smem;
     uint8_t *buf1 = smem + buf_bytes;
-    uint16_t *s_bad = reinterpret_cast<uint16_t *>(smem + 2 * buf_bytes); // 256 x u16
-    uint16_t *s_good = s_bad + 256;                                        // m x u16
-    uint8_t *s_pat = reinterpret_cast<uint8_t *>(s_good + ((m + 7) & ~7u)); // m bytes
-
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lane = tid & 63;
-
-    // text bytes >= 0x80 cannot occur in an ASCII pattern: skip the whole window
-    // WALK 2: the entry of the pattern's last character is 0 ("stop here, compare"),
-    // the classic skip-loop encoding; its real shift stays in the scalar b_last.
-    for (uint32_t i = tid; i < 256; i += BLOCK) {
-        uint16_t v = i < 128 ? a.tab.bad[i] : (uint16_t)m;
-        if (WALK == 2 && i == a.tab.pat[m - 1]) v = 0;
-        s_bad[i] = v;
-    }
-    for (uint32_t i = tid; i < m; i += BLOCK) {
-        s_good[i] = a.tab.good[i];
-        s_pat[i] = a.tab.pat[i];
-    }
-
-    // wave-uniform constants of the WALK 1 fast path (scalar registers)
-    uint32_t p4 = 0, g1 = 0, g2 = 0, g3 = 0, b_last = 0;
-    if (WALK == 2) b_last = a.tab.bad[a.tab.pat[m - 1] & 127];
-    if (WALK == 2) {
-        p4 = (uint32_t)a.tab.pat[m - 4] | ((uint32_t)a.tab.pat[m - 3] << 8) | ((uint32_t)a.tab.pat[m - 2] << 16) |
-             ((uint32_t)a.tab.pat[m - 1] << 24);
-        g1 = a.tab.good[1];
-        g2 = a.tab.good[2];
-        g3 = a.tab.good[3];
-    }
+    const LdsTables tb = load_tables<WALK == 2>(a, smem + 2 * buf_bytes, tid, BLOCK);
 
     const uint32_t nchunk = buf_bytes >> 4; // 16-B chunks per tile incl. halo
     auto issue_tile = [&](uint64_t t, uint8_t *dst) {
@@ -245,69 +137,8 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
         const uint64_t rem = a.own_end - tile_off; // > 0 because t < tile_end
         if (rem < (uint64_t)hi) hi = (uint32_t)rem;
 
-        if (MODE != 1 && !is_loader && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi) {
-            uint32_t i = lo + m - 1;          // index of the window's last character
-            const uint32_t ilim = hi + m - 1; // exclusive
-            if (WALK == 2) {
-                // m >= 4.  Skip loop, two windows per round: s_bad[c] is the k == 0 shift
-                // (kernel1.cl:28,30) for every character but the pattern's last one, whose
-                // entry is 0 -- the walker then stays on that window and the second lookup
-                // sees the same 0.  Only windows whose last character matches leave the
-                // loop body's straight line.  The second lookup may run up to m-1 bytes
-                // past the lane's segment (and, for the last lane, past the tile buffer
-                // into the next LDS region): harmless, such a window is never reported.
-                while (i < ilim) {
-                    i += s_bad[T[i]];
-                    const uint32_t b2 = s_bad[T[i]];
-                    i += b2;
-                    if (b2 == 0 && i < ilim) {
-                        // last character equal: k >= 1.  The next three come from three
-                        // independent byte reads; good[1..3] sit in scalar registers.
-                        const uint32_t c1 = T[i - 1], c2 = T[i - 2], c3 = T[i - 3];
-                        const uint32_t diff = (c3 | (c2 << 8) | (c1 << 16)) ^ (p4 & 0x00FFFFFFu);
-                        uint32_t k;
-                        int d2;
-                        if (__builtin_expect(diff == 0, 0)) {
-                            k = 4; // kernel1.cl:20-22, continued byte-wise
-                            while (k < m && T[i - k] == s_pat[m - 1 - k]) ++k;
-                            if (k == m) { // kernel1.cl:24
-                                const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-                                emit_hit(a, astart - a.first, astart + a.out_bias);
-                                i += 1;
-                                continue;
-                            }
-                            d2 = (int)s_good[k];
-                        } else {
-                            k = (uint32_t)__clz((int)diff) >> 3; // the top byte is 0: 1..3
-                            d2 = k == 1 ? (int)g1 : (k == 2 ? (int)g2 : (int)g3);
-                        }
-                        const int d1 = (int)b_last - (int)k > 1 ? (int)b_last - (int)k : 1; // kernel1.cl:28
-                        i += (uint32_t)(d1 > d2 ? d1 : d2);                                   // kernel1.cl:29-32
-                    }
-                }
-            } else {
-                const uint32_t plast = s_pat[m - 1];
-                while (i < ilim) {
-                    const uint32_t c = T[i];
-                    const uint32_t b = s_bad[c];
-                    if (c != plast) { // k == 0: shift = max(bad[c] - 0, 1), kernel1.cl:28,30
-                        i += b;
-                        continue;
-                    }
-                    uint32_t k = 1; // kernel1.cl:20-22
-                    while (k < m && T[i - k] == s_pat[m - 1 - k]) ++k;
-                    if (k == m) { // kernel1.cl:24
-                        const uint64_t astart = tile_off + (uint64_t)(i - (m - 1)); // aligned coordinate
-                        emit_hit(a, astart - a.first, astart + a.out_bias);
-                        i += 1;
-                        continue;
-                    }
-                    const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28
-                    const int d2 = (int)s_good[k];                              // kernel1.cl:29
-                    i += (uint32_t)(d1 > d2 ? d1 : d2);                         // kernel1.cl:31
-                }
-            }
-        }
+        if (MODE != 1 && !is_loader && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi)
+            walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
         if (MODE == 5) {
             const unsigned long long x = stamp();
             st_walk += x - st_prev;

@@ -28,106 +28,9 @@
 // __syncthreads() would make hipcc drain vmcnt to 0 while a DMA is in flight.
 #pragma once
 
-#include "bmx_scan_kernel.h"
+#include "bmx_scan_common.h"
 
 namespace bmx {
-
-struct LdsTables {
-    const uint16_t *bad;  // 256 x u16 (entry of the pattern's last character: 0 if SKIP)
-    const uint16_t *good; // m x u16
-    const uint8_t *pat;   // m bytes
-    uint32_t m;
-    // scalar copies for the skip-loop walker
-    uint32_t b_last, p3, g1, g2, g3;
-    bool m4;
-};
-
-// One lane walks the window starts [lo, hi) of the tile at T (tile-local indices).
-// SKIP = false: the reference's loop as it stands (kernel1.cl:15-34), one window per
-// round.  SKIP = true: skip loop, two windows per round; the table entry of the
-// pattern's last character is 0, so a window that ends in it stops the walker there;
-// k = 1..3 then comes from three byte reads against scalar registers.
-template <bool SKIP>
-__device__ __forceinline__ void walk_lane(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
-                                          uint32_t hi, uint64_t tile_off)
-{
-    const uint32_t m = tb.m;
-    uint32_t i = lo + m - 1;          // index of the window's last character
-    const uint32_t ilim = hi + m - 1; // exclusive
-    if (!SKIP) {
-        const uint32_t plast = tb.pat[m - 1];
-        while (i < ilim) {
-            const uint32_t c = T[i];
-            const uint32_t b = tb.bad[c];
-            if (c != plast) { // k == 0: shift = max(bad[c] - 0, 1), kernel1.cl:28,30
-                i += b;
-                continue;
-            }
-            uint32_t k = 1; // kernel1.cl:20-22
-            while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
-            if (k == m) { // kernel1.cl:24
-                const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-                emit_hit(a, astart - a.first, astart + a.out_bias);
-                i += 1;
-                continue;
-            }
-            const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28
-            const int d2 = (int)tb.good[k];                             // kernel1.cl:29
-            i += (uint32_t)(d1 > d2 ? d1 : d2);                         // kernel1.cl:31
-        }
-    } else {
-        while (i < ilim) {
-            i += tb.bad[T[i]];
-            const uint32_t b2 = tb.bad[T[i]]; // may look up to m-1 bytes past the segment: never reported
-            i += b2;
-            if (b2 == 0 && i < ilim) {
-                uint32_t k = 1;
-                int d2 = 0;
-                bool have_k = false;
-                if (tb.m4) {
-                    const uint32_t c1 = T[i - 1], c2 = T[i - 2], c3 = T[i - 3];
-                    const uint32_t diff = (c3 | (c2 << 8) | (c1 << 16)) ^ tb.p3;
-                    if (diff != 0) {
-                        k = (uint32_t)__clz((int)diff) >> 3; // top byte is 0: k = 1..3
-                        d2 = k == 1 ? (int)tb.g1 : (k == 2 ? (int)tb.g2 : (int)tb.g3);
-                        have_k = true;
-                    } else {
-                        k = 4;
-                    }
-                }
-                if (!have_k) {
-                    while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
-                    if (k == m) {
-                        const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-                        emit_hit(a, astart - a.first, astart + a.out_bias);
-                        i += 1;
-                        continue;
-                    }
-                    d2 = (int)tb.good[k];
-                }
-                const int d1 = (int)tb.b_last - (int)k > 1 ? (int)tb.b_last - (int)k : 1;
-                i += (uint32_t)(d1 > d2 ? d1 : d2);
-            }
-        }
-    }
-}
-
-// wait until at most n of this wave's vector-memory operations are outstanding
-__device__ __forceinline__ void wait_vmcnt_at_most(uint32_t n)
-{
-    switch (n) { // wave-uniform
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
 
 // BLOCK threads, SEG window starts per lane (4 * odd), AUX DMA cache policy,
 // SKIP walker choice, MODE 0 product / 5 stamps (diagnostic).
@@ -146,43 +49,12 @@ __global__ __launch_bounds__(BLOCK) void scan_ring_kernel(const ScanArgs a_in)
     const ScanArgs &a = a_in;
     extern __shared__ uint4 smem_u4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(smem_u4);
-    const uint32_t m = a.m;
     const uint32_t buf_bytes = TILE + a.halo16;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lane = tid & 63;
 
-    uint16_t *s_bad = reinterpret_cast<uint16_t *>(smem + 3ull * buf_bytes);
-    uint16_t *s_good = s_bad + 256;
-    uint8_t *s_pat = reinterpret_cast<uint8_t *>(s_good + ((m + 7) & ~7u));
-
-    const uint32_t last_char = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 1]);
-    for (uint32_t i = tid; i < 256; i += BLOCK) {
-        uint16_t v = i < 128 ? a.tab.bad[i] : (uint16_t)m; // text bytes >= 0x80 are not in an ASCII pattern
-        if (SKIP && i == last_char) v = 0;
-        s_bad[i] = v;
-    }
-    for (uint32_t i = tid; i < m; i += BLOCK) {
-        s_good[i] = a.tab.good[i];
-        s_pat[i] = a.tab.pat[i];
-    }
-    LdsTables tb;
-    tb.bad = s_bad;
-    tb.good = s_good;
-    tb.pat = s_pat;
-    tb.m = m;
-    tb.m4 = m >= 4;
-    tb.b_last = tb.p3 = tb.g1 = tb.g2 = tb.g3 = 0;
-    if (SKIP) { // scalar registers, loaded and waited for HERE (a pending load would drain the DMA later)
-        tb.b_last = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.bad[last_char & 127]);
-        if (tb.m4) {
-            tb.p3 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 4] | ((uint32_t)a.tab.pat[m - 3] << 8) |
-                                                   ((uint32_t)a.tab.pat[m - 2] << 16));
-            tb.g1 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.good[1]);
-            tb.g2 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.good[2]);
-            tb.g3 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.good[3]);
-        }
-    }
+    const LdsTables tb = load_tables<SKIP>(a, smem + 3ull * buf_bytes, tid, BLOCK);
     __syncthreads();
 
     // DMA of one tile: ninstr wave-instructions of 1 KiB, instruction j issued by wave j % WAVES.

@@ -26,7 +26,7 @@
 // bmx_scan_kernel.h for the line-by-line mapping).
 #pragma once
 
-#include "bmx_scan_kernel.h"
+#include "bmx_scan_common.h"
 
 namespace bmx {
 
@@ -51,33 +51,12 @@ __global__ __launch_bounds__(WAVES * 64) void scan_wave_kernel(const ScanArgs a_
     const uint32_t lane = tid & 63;
 
     uint8_t *wbuf = smem + (uint64_t)wave * NBUF * buf_bytes; // this wave's buffers
-    uint16_t *s_bad = reinterpret_cast<uint16_t *>(smem + (uint64_t)WAVES * NBUF * buf_bytes); // 256 x u16
-    uint16_t *s_good = s_bad + 256;                                                            // m x u16
-    uint8_t *s_pat = reinterpret_cast<uint8_t *>(s_good + ((m + 7) & ~7u));                    // m bytes
-
-    const uint32_t last_char = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 1]);
-    for (uint32_t i = tid; i < 256; i += BLOCK) {
-        uint16_t v = i < 128 ? a.tab.bad[i] : (uint16_t)m; // bytes >= 0x80: not in an ASCII pattern
-        if (i == last_char) v = 0;                          // stop-and-compare marker
-        s_bad[i] = v;
-    }
-    for (uint32_t i = tid; i < m; i += BLOCK) {
-        s_good[i] = a.tab.good[i];
-        s_pat[i] = a.tab.pat[i];
-    }
-    // wave-uniform constants, forced into scalar registers here: readfirstlane makes
-    // the compiler wait for these loads NOW; left pending, their first use inside the
-    // walk would cost an s_waitcnt vmcnt(0) that also drains the DMA in flight
-    const uint32_t b_last = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.bad[last_char & 127]);
-    const bool m4 = m >= 4;
-    uint32_t p3 = 0, g1 = 0, g2 = 0, g3 = 0;
-    if (m4) { // the three characters before the last, and good[1..3]
-        p3 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 4] | ((uint32_t)a.tab.pat[m - 3] << 8) |
-                                            ((uint32_t)a.tab.pat[m - 2] << 16));
-        g1 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.good[1]);
-        g2 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.good[2]);
-        g3 = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.good[3]);
-    }
+    // tables into LDS behind the waves' buffers; skip-loop encoding (entry of the last character = 0)
+    const LdsTables tb = load_tables<true>(a, smem + (uint64_t)WAVES * NBUF * buf_bytes, tid, BLOCK);
+    const uint16_t *s_bad = tb.bad, *s_good = tb.good;
+    const uint8_t *s_pat = tb.pat;
+    const uint32_t b_last = tb.b_last, p3 = tb.p3, g1 = tb.g1, g2 = tb.g2, g3 = tb.g3;
+    const bool m4 = tb.m4;
     __syncthreads(); // tables visible; the only workgroup barrier of the kernel
 
     // DMA of one piece: CH wave-instructions of 1 KiB.  With SEG = 16k+4 the count
