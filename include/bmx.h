@@ -147,7 +147,8 @@ float bmx_last_scan_ms(bmx_ctx *ctx);
  * ring of 64 event pairs: lets a benchmark time K searches without synchronising
  * on an event inside its timed region.  Returns the number written (<= max_n). */
 int bmx_scan_ms_history(bmx_ctx *ctx, float *ms_out, int32_t max_n);
-/* Scan-kernel launch geometry for pattern length m: out[0]=grid (workgroups),
+/* Scan-kernel launch geometry for pattern length m (of the explicitly chosen variant, else
+ * of the variant the most recent search picked): out[0]=grid (workgroups),
  * out[1]=threads per workgroup, out[2]=window starts per synchronisation unit
  * (workgroup tile or wave piece), out[3]=LDS bytes per workgroup, out[4]=window
  * starts per lane, out[5]=kernel kind (0 workgroup tiles, 1 wave streams, 2 three-buffer ring). */

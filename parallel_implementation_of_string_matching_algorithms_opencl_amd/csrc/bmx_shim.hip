@@ -75,8 +75,9 @@ struct Variant {
 const Variant g_variants[] = {
     // ---- products (every one parity-tested by tests/test_gpu_parity.py) ----
     BMX_TILE(1024, 68, 2, 0, 0),        // 0: default -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
-    BMX_TILE(1024, 68, 2, 0, 2),        // 1: same tile, skip-loop walker (picked automatically for small alphabets)
-    BMX_TILE(1024, 52, 2, 0, 0),        // 2
+    BMX_TILE(1024, 68, 2, 0, 2),        // 1: same tile, skip-loop walker
+    BMX_TILE(1024, 36, 2, 0, 2),        // 2: skip-loop walker, 36 KiB tiles, TWO workgroups = 32 waves per CU
+                                        //    (picked automatically for small alphabets)
     BMX_TILE(768, 100, 2, 0, 0),        // 3
     BMX_TILE(256, 132, 2, 0, 0),        // 4: two workgroups per CU
     BMX_TILE(256, 132, 0, 0, 0),        // 5: default cache policy -- the first kernel of round 1
@@ -106,7 +107,8 @@ struct bmx_ctx {
     int device = 0;
     int num_cu = 256;
     int variant = 0;
-    bool auto_walker = true; // until bmx_set_variant(): variant 0 or 1 by the pattern's alphabet
+    bool auto_walker = true; // until bmx_set_variant(): variant 0 or 2 by the pattern's alphabet
+    int last_variant = 0;    // what the most recent search ran (bmx_scan_geometry reports it)
     int ed_variant = 0;      // edit-distance tile shape (bmx_set_ed_variant)
     float ed_last_ms = -1.0f;
     int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
@@ -153,10 +155,14 @@ int blocks_per_cu_for(const bmx_ctx *ctx, const Variant &v, int32_t m)
     return b;
 }
 
-// Default walker choice.  On small alphabets (DNA: 4 symbols) almost every window ends in
-// a character of the pattern, shifts are a few bytes and the skip-loop walker is 1.7x
-// faster (2.06 vs 1.2 TB/s on 4 GiB ACGT, m = 64); on wide alphabets the byte-wise walker
-// is ~2 % ahead.  The text is unknown here, the pattern's own alphabet is the hint.
+// Default kernel choice.  On small alphabets (DNA: 4 symbols) almost every window ends in
+// a character of the pattern and shifts are a few bytes: the walkers, not HBM, bound the
+// scan.  There the skip-loop walker is 1.7x faster than the byte-wise one and twice the
+// waves per CU (two workgroups on 36 KiB tiles) another 1.2x (4 GiB ACGT, m = 64:
+// 1.2 -> 2.0 -> 2.3-2.4 TB/s); a "quad" walker (text[i-3..i] by one aligned ds_read2_b32 +
+// v_alignbyte, k from XOR/clz) tied with it and a two-streams-per-lane version of that was
+// 40 % slower, so neither is kept.  On wide alphabets the byte-wise walker on 68 KiB tiles
+// is ahead.  The text is unknown here, the pattern's own alphabet is the hint.
 uint32_t lds_bytes_for(const Variant &v, int32_t m);
 
 int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m)
@@ -171,7 +177,7 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m)
             seen[(unsigned char)pat[i]] = true;
             ++distinct;
         }
-    return distinct <= 8 ? 1 : 0;
+    return distinct <= 8 ? 2 : 0;
 }
 
 // Convert the caller's int32 tables (or build them) into the kernel-argument layout.
@@ -280,7 +286,7 @@ int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu)
 int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6])
 {
     if (!ctx || !out || m < 1 || m > BMX_MAX_PATTERN) return BMX_ERR_ARG;
-    const Variant &v = g_variants[ctx->variant];
+    const Variant &v = g_variants[ctx->auto_walker ? ctx->last_variant : ctx->variant];
     out[0] = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
     out[1] = v.block;
     out[2] = unit_bytes(v);
@@ -334,6 +340,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
 
     if (n_starts > 0) {
         const int vi = pick_variant(ctx, pat, m);
+        ctx->last_variant = vi;
         const Variant &v = g_variants[vi];
         const uint64_t tile = unit_bytes(v);
         const uintptr_t addr = (uintptr_t)d_text;
