@@ -140,6 +140,10 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks all on cuda:0 with the exchange staged through host memory on gloo "
+                         "(RCCL refuses duplicate devices): exercises the multi-rank code path on a 1-GPU box; "
+                         "its numbers mean nothing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,11 +154,18 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
         sys.exit(2)
+    rehearse = args.rehearse_on_one_gpu and world > 1
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearse else dev  # where the small control collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.workload == "ed64k":  # BASELINE config 5 (secondary: the reference's second algorithm)
         return bench_edit_distance(args, dev, local_rank)
@@ -177,7 +188,7 @@ def main():
 
     state = {}
     if world > 1:
-        xchg = shard.SlotExchange(ctx, world, rank, dev, slot=SLOT)  # [count | offsets...] slots over RCCL
+        xchg = shard.SlotExchange(ctx, world, rank, dev, slot=SLOT, via_host=rehearse)  # [count | offsets...] over RCCL
         out = xchg.out
     else:
         xchg = None
@@ -205,7 +216,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -222,7 +233,7 @@ def main():
     scan_ms = ctx.scan_ms_history(min(args.steps, 64))
     avg_scan_ms = float(np.mean(scan_ms))
     if world > 1:  # roofline of the slowest rank's kernel
-        t = torch.tensor([avg_scan_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([avg_scan_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         avg_scan_ms = float(t.item())
     achieved = n_own / (avg_scan_ms * 1e-3) / 1e9  # algorithmic bytes per launch: 1 B per owned text byte
@@ -236,7 +247,8 @@ def main():
         "config": {"workload": spec.name, "text_bytes_total": spec.n, "text_bytes_per_gpu": n_own,
                    "pattern_bytes": m, "alphabet": "printable-95" if spec.kind == 0 else "ACGT",
                    "matches": int(result.size), "sharding": f"{world} contiguous shard(s) + {m - 1} B halo",
-                   "exchange": "RCCL all-gather of [count|offsets] slots" if world > 1 else "none",
+                   "exchange": ("REHEARSAL on one GPU, gloo via host" if rehearse else
+                                "RCCL all-gather of [count|offsets] slots") if world > 1 else "none",
                    "kernel": f"{geom['kind']} block {geom['block']} seg {geom['seg']} grid {geom['grid']} "
                              f"lds {geom['lds_bytes']}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -92,3 +92,25 @@ def test_sharded_scan_dense_result_takes_exact_exchange(port, ctx):
     assert want.size > 2 * 256
     got = _run(2, spec_args, slot=256)
     assert np.array_equal(got, want)
+
+
+def test_bench_multi_rank_path_rehearsal(ctx):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per
+    rank), with both ranks on the one GPU of the box and the exchange on gloo: the same
+    Python path as on 2/4/8 GPUs except for the RCCL call itself."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--gib-per-gpu", "0.25", "--rehearse-on-one-gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["unit"] == "GB/s"
+    assert line["parity"]["planted_offsets_exact"] is True
+    assert line["config"]["text_bytes_total"] == 2 * line["config"]["text_bytes_per_gpu"]
+    assert line["config"]["matches"] > 500 and line["roofline"]["bound"] == "hbm"
