@@ -1,5 +1,5 @@
 """One-off stress run (not part of the test suite): many seeded (text, pattern) cases x every
-product kernel variant against the CPU oracle.  python tools/stress_parity.py --cases 300"""
+product kernel variant against the CPU oracle.  python tests/stress_parity.py --cases 300"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

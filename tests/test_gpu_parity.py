@@ -333,6 +333,26 @@ def test_full_size_configs_find_exactly_the_planted_offsets(ctx, port, name):
     torch.cuda.empty_cache()
 
 
+def test_text_beyond_4GiB_uses_64bit_offsets(ctx, port):
+    """6 GiB in one buffer: offsets past 2^32 (the reference's indices are int)."""
+    import torch
+
+    spec = corpus.CorpusSpec("6GiB", 6 * (1 << 30) + 12345, 16, 0, 0x5EED0009, 1 << 22, 1 << 28, -1)
+    d_text = spec.device_text(ctx)
+    pos, total = ctx.search_device(d_text, spec.pattern(), capacity=1 << 16)
+    got = pos.cpu().numpy().astype(np.uint64)
+    want = spec.planted_offsets()
+    assert total == want.size and np.array_equal(got, want)
+    assert int(got[-1]) == spec.n - spec.m and (got > np.uint64(1 << 32)).sum() > 400
+    # the bytes around 2^32 against the oracle
+    a = (1 << 32) - (1 << 20)
+    chunk = d_text[a:a + (2 << 20)].cpu().numpy()
+    ow = port.search(chunk, spec.pattern()) + np.uint64(a)
+    assert np.array_equal(ow, got[(got >= a) & (got <= a + (2 << 20) - spec.m)])
+    del d_text
+    torch.cuda.empty_cache()
+
+
 def test_full_size_shard_of_config4(ctx):
     """Config 4 is 8 x 4 GiB; one GPU can hold any one shard: scan shard 5 (with its
     halo) of the 32 GiB corpus and compare with the plants that fall inside it."""
