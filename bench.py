@@ -114,7 +114,13 @@ def bench_edit_distance(args, dev, local_rank):
             "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "ed64k", "rows": n, "cols": n, "alphabet": "ACGT", "distance": int(d),
                        "device_ms": round(float(np.mean(kern_ms)), 3)},
-            "roofline": None}
+            # integer VALU roofline: 256 CUs x 4 SIMD-32 x 32 lanes/clk x 2.4 GHz = 78.6 T lane-ops/s, 4 VALU
+            # instructions per cell (v_cmp, v_addc, v_min3, v_add) -> 19,661 G cells/s.  The kernel is nowhere
+            # near it: a DP wavefront has at most 256-512 independent tiles in flight and each wave is bound by
+            # its own instruction issue.
+            "roofline": {"bound": "valu-int32", "achieved": round(n * n / (float(np.mean(kern_ms)) * 1e-3) / 1e9, 1),
+                         "peak": 19661.0, "unit": "GCUPS",
+                         "frac": round(n * n / (float(np.mean(kern_ms)) * 1e-3) / 1e9 / 19661.0, 4), "traffic": None}}
     if not args.no_cpu_baseline:
         import oracle  # reported baseline + checker only
 
