@@ -20,15 +20,10 @@
 //    step; up and diagonal values never leave the lane's registers.
 //  * Integer min/add only; no MFMA (a DP recurrence is not a contraction).
 //
-// Measured (MI355X, 64k x 64k): 23-25 ms = 170-185 GCUPS; rocprofv3 shows ~50 us per
-// 256 x 256 tile launch = ~320 cycles per step: the ONE wave of a CU issues an instruction
-// every ~6 cycles whether dependent or not, and the chain of dependent tile diagonals is
-// the critical path (at most 256 of 1024 SIMDs are busy).  The lean step (52 instead of
-// ~70 instructions) gained 3 %, fetching the row character one step ahead LOST 12 % (its
-// index clamp costs more instructions than the LDS latency it hides): instruction count
-// per step is the only lever inside this schedule; the next one is the schedule itself
-// (persistent workgroups with 64-row hand-offs instead of one launch per tile diagonal:
-// 98k instead of 163k steps on the critical path).
+// Measured (MI355X, 64k x 64k): 17.4 ms = 247 GCUPS with 256 x 256 tiles (first version,
+// LEAN = false: 25.5 ms).  Bound by ONE wave's instruction issue along the chain of 511
+// dependent tile diagonals (at most 256 of 1024 SIMDs are busy): the steady-state step is
+// 30 instructions for 256 cells.  DESIGN.md s7 has the step-time model and what is next.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -50,10 +45,8 @@ struct EdArgs {
 };
 
 // LEAN = false: the first version (shuffle through ds_bpermute, every step predicated).
-// LEAN = true: fewer instructions per step -- the tile's steps are split into ramp-up,
-// steady state (every lane inside the tile: no predication at all) and ramp-down; the
-// left neighbour's value moves by one DPP wave_shr:1, lane 0's boundary value comes out
-// of a register by v_readlane; the cell update is min3(left, up, diag - 1 + ne) + 1,
+// LEAN = true: fewer instructions per step (see the comment at the loop); the cell update
+// is min3(left, up, diag - 1 + ne) + 1,
 // which equals the reference's "equal ? diag : 1 + min3" on every valid table because
 // neighbouring cells differ by at most 1 (so diag <= left + 1 and diag <= up + 1).
 template <int C, int R, bool LEAN = false>
@@ -102,57 +95,63 @@ __global__ __launch_bounds__(64) void ed_tile_kernel(const EdArgs a)
     __syncthreads();
 
     if (LEAN) {
-        uint32_t last = 0;                     // my right-most value of the previous step
-        uint32_t blk_left = 0, blk_right = 0;  // 64 rows' worth of boundary values, one per lane
-        auto step = [&](uint32_t s, auto check_tag) {
+        // State per lane: H[C] (the row above, updated in place), diag_in, `last` (my right-most
+        // value, what lane+1 reads next step) and `bc` (the row character, which flows to the
+        // right with the rows).  Both hand-overs are one DPP wave_shr:1 each; lane 0's inputs
+        // (left boundary value, fresh row character) come out of per-64-row registers by
+        // v_readlane with the wave-uniform step index.  The cell updates of a step run under the
+        // EXEC mask of the lanes that are inside the tile (ramp-up: lanes <= s; ramp-down:
+        // lanes >= s-rows+1) -- no per-value predication, and no mask at all in the steady state.
+        // Lane 63 stores its value to s_right[row]; every other lane stores to a dummy word of
+        // its own (address selected by a per-lane constant mask): no branch for one lane.
+        __shared__ uint32_t s_dummy[64];
+        uint32_t last = 0, bc = 0;
+        uint32_t blk_left = 0, blk_b = 0; // 64 rows' worth, one per lane
+        const uint32_t m63 = lane == 63 ? ~0u : 0u;
+        const uint32_t waddr0 = lane == 63 ? (uint32_t)(uintptr_t)(s_right) - 63u * 4u
+                                           : (uint32_t)(uintptr_t)(s_dummy + lane); // LDS byte addresses
+        auto step = [&](uint32_t s, uint32_t j, auto check_tag) {
             constexpr bool CHECK = decltype(check_tag)::value;
-            const uint32_t j = s & 63;
-            if (j == 0) { // lane 0 enters a new block of 64 rows (wave-uniform branch)
-                const uint32_t r = s + lane;
-                blk_left = r < rows ? s_left[r] : 0;
-            }
-            const uint32_t left0 = __builtin_amdgcn_readlane(blk_left, j); // lane 0's left input
+            const bool active = !CHECK || (lane <= s && lane + rows > s);
+            // the two shifts run with every lane enabled: DPP does not read a lane that EXEC has
+            // switched off, and in the ramp-down the lowest active lane's neighbour is one
+            const uint32_t left0 = __builtin_amdgcn_readlane(blk_left, j);
+            const uint32_t bc0 = __builtin_amdgcn_readlane(blk_b, j);
             uint32_t left = __builtin_amdgcn_update_dpp(left0, last, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-            const int32_t rr = (int32_t)s - (int32_t)lane;
-            const bool active = !CHECK || (rr >= 0 && rr < (int32_t)rows);
-            const uint32_t bc = s_b[CHECK ? (active ? (uint32_t)rr : 0u) : (uint32_t)rr];
-            uint32_t diag = diag_in;
-            const uint32_t left_in = left;
-            uint32_t v = 0;
-            uint32_t Hn[C];
-#pragma unroll
-            for (int k = 0; k < C; ++k) {
-                const uint32_t up = H[k];
-                const int32_t x = (int32_t)diag - 1 + (bc != ac[k] ? 1 : 0);
-                int32_t mi = (int32_t)left < (int32_t)up ? (int32_t)left : (int32_t)up;
-                mi = mi < x ? mi : x;
-                v = (uint32_t)(mi + 1); // = bc == ac[k] ? diag : 1 + min3 (kernal.cl:34-53) on a valid table
-                diag = up;
-                left = v;
-                Hn[k] = v;
-            }
+            bc = __builtin_amdgcn_update_dpp(bc0, bc, 0x138, 0xF, 0xF, false);
             if (active) {
+                uint32_t diag = diag_in;
+                diag_in = left; // next row's diagonal = this row's left input
 #pragma unroll
-                for (int k = 0; k < C; ++k) H[k] = Hn[k];
-                diag_in = left_in;
-                last = v;
-            }
-            if (s >= 63) { // lane 63 is at row s-63: collect its value, flush 64 at a time
-                const uint32_t r63 = s - 63;
-                const uint32_t v63 = __builtin_amdgcn_readlane(last, 63);
-                blk_right = lane == (r63 & 63) ? v63 : blk_right;
-                if ((r63 & 63) == 63 || r63 + 1 == rows) {
-                    const uint32_t r = (r63 & ~63u) + lane;
-                    if (r < rows) s_right[r] = blk_right;
+                for (int k = 0; k < C; ++k) {
+                    const uint32_t up = H[k];
+                    const int32_t x = (int32_t)diag - 1 + (bc != ac[k] ? 1 : 0);
+                    int32_t mi = (int32_t)left < (int32_t)up ? (int32_t)left : (int32_t)up;
+                    mi = mi < x ? mi : x;
+                    left = (uint32_t)(mi + 1); // = bc == ac[k] ? diag : 1 + min3 (kernal.cl:34-53) on a valid table
+                    diag = up;
+                    H[k] = left;
                 }
+                last = left;
+                // lane 63 (row s-63) -> s_right[s-63]; the others -> their dummy word
+                const uint32_t waddr = waddr0 + ((s * 4u) & m63);
+                *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(waddr) = left;
             }
         };
         const uint32_t steps = rows + 63;
-        const uint32_t ramp = steps < 63 ? steps : 63;
-        uint32_t s = 0;
-        for (; s < ramp; ++s) step(s, std::true_type{});
-        for (; s < rows; ++s) step(s, std::false_type{}); // 63 <= s < rows: all 64 lanes inside the tile
-        for (; s < steps; ++s) step(s, std::true_type{});
+        for (uint32_t s0 = 0; s0 < steps; s0 += 64) {
+            // rows [s0, s0+64) enter at lane 0 during this block
+            const uint32_t r = s0 + lane;
+            blk_left = r < rows ? s_left[r] : 0;
+            blk_b = r < rows ? s_b[r] : 0;
+            const uint32_t n = steps - s0 < 64 ? steps - s0 : 64;
+            if (s0 >= 63 && s0 + 63 < rows) { // every lane is inside the tile for these 64 steps
+#pragma unroll 2
+                for (uint32_t j = 0; j < 64; ++j) step(s0 + j, j, std::false_type{});
+            } else {
+                for (uint32_t j = 0; j < n; ++j) step(s0 + j, j, std::true_type{});
+            }
+        }
     } else {
     uint32_t last = 0; // my right-most value of the previous step (what lane+1 reads)
         const uint32_t steps = rows + 63;

@@ -511,12 +511,14 @@ struct EdVariant {
 };
 #define BMX_ED(C_, R_, LEAN_) {C_, R_, bmx::ed_tile_kernel<C_, R_, LEAN_>}
 const EdVariant g_ed_variants[] = {
-    BMX_ED(4, 128, true),  // 0: default: tiles of 128 rows x 256 columns, lean step
-    BMX_ED(4, 256, true),  // 1
+    BMX_ED(4, 256, true),  // 0: default: tiles of 256 rows x 256 columns, lean step
+    BMX_ED(4, 128, true),  // 1
     BMX_ED(8, 256, true),  // 2
-    BMX_ED(2, 256, true),  // 3
-    BMX_ED(2, 128, true),  // 4
+    BMX_ED(4, 384, true),  // 3
+    BMX_ED(6, 256, true),  // 4
     BMX_ED(4, 256, false), // 5: the first version (ds_bpermute shuffle, predicated steps)
+    BMX_ED(4, 512, true),  // 6
+    BMX_ED(3, 256, true),  // 7
 };
 constexpr int N_ED_VARIANTS = sizeof(g_ed_variants) / sizeof(g_ed_variants[0]);
 } // namespace
