@@ -2,7 +2,7 @@
 """bench.py -- BASELINE.json's metric: GB/s of text scanned, 16-byte pattern over
 4 GiB of synthetic ASCII per MI355X, at 1/2/4/8 GPUs.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -139,8 +139,8 @@ def bench_edit_distance(args, dev, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gib-per-gpu", type=float, default=4.0)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg3b", "ed64k"])
     ap.add_argument("--variant", type=int, default=-1)
