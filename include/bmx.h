@@ -128,10 +128,13 @@ int bmx_count_to_device(bmx_ctx *ctx, uint64_t *d_dst, void *stream);
  * valid offsets to d_merged (ascending globally, because shards are contiguous and
  * each list is ascending), the total to d_total[0] and the largest per-rank count
  * as published to d_total[1].  Counts larger than slot_stride-1 are clamped: a
- * caller that sees d_total[1] > slot_stride-1 falls back to an exact exchange. */
+ * caller that sees d_total[1] > slot_stride-1 falls back to an exact exchange.
+ * d_total has THREE words; `seq` is stored to d_total[2] last with a system-scope
+ * release, so d_total may be pinned host memory that the host polls for `seq`
+ * instead of synchronising the stream. */
 int bmx_merge_gathered_device(bmx_ctx *ctx, const uint64_t *d_gathered, int32_t world,
                               uint64_t slot_stride, uint64_t *d_merged, uint64_t merged_capacity,
-                              uint64_t *d_total, void *stream);
+                              uint64_t *d_total, uint64_t seq, void *stream);
 
 /* Text upload kept apart from the scan (repeated queries on a resident text). */
 int bmx_text_upload(bmx_ctx *ctx, const char *text, uint64_t n, void **d_text_out);

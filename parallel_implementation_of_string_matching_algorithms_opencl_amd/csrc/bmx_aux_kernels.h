@@ -145,7 +145,7 @@ __global__ __launch_bounds__(SMALL_SORT_THREADS) void small_sort_kernel(uint64_t
 // the (at most a few dozen) counts is recomputed by every workgroup.
 // ---------------------------------------------------------------------------
 __global__ void merge_gathered_kernel(const uint64_t *gathered, int world, uint64_t stride, uint64_t *merged,
-                                      uint64_t merged_cap, uint64_t *total_out)
+                                      uint64_t merged_cap, uint64_t *total_out, uint64_t seq)
 {
     const int r = blockIdx.x;
     uint64_t before = 0, mine = 0, total = 0, largest = 0;
@@ -160,6 +160,8 @@ __global__ void merge_gathered_kernel(const uint64_t *gathered, int world, uint6
     if (r == 0 && threadIdx.x == 0) {
         total_out[0] = total;   // matches in the merged list (clamped slots)
         total_out[1] = largest; // largest per-rank count as published: > stride-1 means a slot overflowed
+        // total_out may be pinned host memory that the host polls: the sequence number goes last
+        __hip_atomic_store(&total_out[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const uint64_t *src = gathered + (uint64_t)r * stride + 1;
     for (uint64_t i = threadIdx.x; i < mine; i += blockDim.x)

@@ -483,13 +483,14 @@ int bmx_count_to_device(bmx_ctx *ctx, uint64_t *d_dst, void *stream_v)
 }
 
 int bmx_merge_gathered_device(bmx_ctx *ctx, const uint64_t *d_gathered, int32_t world, uint64_t slot_stride,
-                              uint64_t *d_merged, uint64_t merged_capacity, uint64_t *d_total, void *stream_v)
+                              uint64_t *d_merged, uint64_t merged_capacity, uint64_t *d_total, uint64_t seq,
+                              void *stream_v)
 {
     if (!ctx || !d_gathered || !d_total || world < 1 || slot_stride < 1) return BMX_ERR_ARG;
     if (merged_capacity > 0 && !d_merged) return BMX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(bmx::merge_gathered_kernel, dim3(world), dim3(256), 0, (hipStream_t)stream_v, d_gathered,
-                       (int)world, slot_stride, d_merged, merged_capacity, d_total);
+                       (int)world, slot_stride, d_merged, merged_capacity, d_total, seq);
     HIPCHK(hipGetLastError());
     return BMX_OK;
 }

@@ -56,7 +56,7 @@ SYMBOLS = [
     ("bmx_search_device_finish", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, _u64p, C.c_void_p]),
     ("bmx_count_to_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bmx_merge_gathered_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_uint64,
-                                            C.c_void_p, C.c_void_p]),
+                                            C.c_void_p, C.c_uint64, C.c_void_p]),
     ("bmx_text_upload", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     ("bmx_device_free", C.c_int, [C.c_void_p, C.c_void_p]),
     ("bmx_device_alloc", C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
@@ -266,13 +266,15 @@ class Context:
         stream = C.c_void_p(torch.cuda.current_stream(d_dst.device).cuda_stream)
         _check(lib().bmx_count_to_device(self._h, C.c_void_p(d_dst.data_ptr()), stream), "bmx_count_to_device")
 
-    def merge_gathered(self, gathered, world: int, slot_stride: int, merged, d_total):
+    def merge_gathered(self, gathered, world: int, slot_stride: int, merged, d_total, seq: int = 0):
+        """d_total: 3 x int64, device memory or PINNED host memory (then poll d_total[2] == seq)."""
         import torch
 
         stream = C.c_void_p(torch.cuda.current_stream(gathered.device).cuda_stream)
         _check(lib().bmx_merge_gathered_device(self._h, C.c_void_p(gathered.data_ptr()), world, slot_stride,
                                                C.c_void_p(merged.data_ptr()), merged.numel(),
-                                               C.c_void_p(d_total.data_ptr()), stream), "bmx_merge_gathered_device")
+                                               C.c_void_p(d_total.data_ptr()), seq, stream),
+               "bmx_merge_gathered_device")
 
     def last_scan_ms(self) -> float:
         return float(lib().bmx_last_scan_ms(self._h))

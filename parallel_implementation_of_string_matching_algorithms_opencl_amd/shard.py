@@ -81,7 +81,10 @@ class SlotExchange:
         self.out = self.buf[1:]  # the search writes its ascending offsets here
         self.gathered = torch.zeros(world * (slot + 1), dtype=torch.int64, device=device)
         self.merged = torch.zeros(world * slot, dtype=torch.int64, device=device)
-        self.totals = torch.zeros(2, dtype=torch.int64, device=device)
+        # {total, largest per-rank count, sequence number}: pinned host memory that the merge kernel
+        # writes directly and run() polls -- no D2H copy, no stream synchronisation per step
+        self.totals = torch.zeros(3, dtype=torch.int64).pin_memory()
+        self.seq = 0
         self.last_counts = None
 
     def run(self, query):
@@ -98,9 +101,15 @@ class SlotExchange:
             self.gathered.copy_(hg)
         else:
             dist.all_gather_into_tensor(self.gathered, self.buf, group=self.group)
-        self.ctx.merge_gathered(self.gathered, self.world, self.slot + 1, self.merged, self.totals)
+        self.seq += 1
+        self.ctx.merge_gathered(self.gathered, self.world, self.slot + 1, self.merged, self.totals, self.seq)
         local_total = query.finish()
-        total, largest = (int(x) for x in self.totals.cpu())  # the step's one stream synchronisation
+        spins = 0
+        while int(self.totals[2]) != self.seq:  # written last by the merge kernel (system-scope release)
+            spins += 1
+            if spins > 50_000_000:
+                raise RuntimeError("SlotExchange: merge kernel never published its totals")
+        total, largest = int(self.totals[0]), int(self.totals[1])
         if largest > self.slot:  # dense result somewhere: exact exchange (every rank takes this branch)
             full = torch.empty(max(local_total, 1), dtype=torch.int64, device=self.buf.device)
             exact = self.ctx.prepare(query.d_text, query._pat, full, n=query.n, n_own=query.n_own,
