@@ -136,13 +136,56 @@ def bench_edit_distance(args, dev, local_rank):
         sys.exit(1)
 
 
+def bench_suffix_array(args, dev, local_rank):
+    """Suffix array of a 2 MiB text shaped like the reference's corpus (SuffixArrays/input2M.txt: one
+    paragraph repeated, so prefix doubling needs all ~log2(n) rounds).  A step is one construction
+    with the text resident; characters per second."""
+    n = 2 << 20
+    para = corpus.stream_bytes(0, 509, 0x5EED0006, 0)  # 509 printable bytes, repeated
+    para = np.where(para == 96, 95, para).astype(np.uint8)  # character 96 ties in the reference (bmx.h)
+    x = np.tile(para, n // para.size + 1)[:n].copy()
+    ctx = host.Context(local_rank)
+    dx = torch.from_numpy(x).to(dev)
+    steps = min(args.steps, 50)
+    for _ in range(min(args.warmup, 3)):
+        sa = ctx.suffix_array_device(dx)
+    torch.cuda.synchronize()
+    dev_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sa = ctx.suffix_array_device(dx)
+        dev_ms.append(ctx.last_suffix_array_ms())
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    line = {"metric": "suffix-array construction, 2 MiB repeated-paragraph text, 1x MI355X", "value":
+            round(n * steps / elapsed / 1e6, 1), "unit": "Mchar/s", "n_gpus": 1, "steps": steps,
+            "warmup": min(args.warmup, 3), "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "sa2m", "chars": n, "period": int(para.size), "rounds": ctx.last_suffix_array_rounds(),
+                       "device_ms": round(float(np.mean(dev_ms)), 3)}, "roofline": None}
+    if not args.no_cpu_baseline:
+        import oracle  # reported baseline + checker only
+
+        chk = oracle.reference() or oracle.port()
+        t0 = time.perf_counter()
+        want = chk.suffix_array(x)
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(n / dt / 1e6, 2), "unit": "Mchar/s", "cores": 1, "kind": chk.kind,
+                                "sample": f"one construction of the same 2 MiB text, {dt:.1f} s"}
+        line["parity"] = {"suffix_array_equals_cpu": bool(np.array_equal(sa.cpu().numpy(), want))}
+    print(json.dumps(line), flush=True)
+    ctx.close()
+    if "parity" in line and not line["parity"]["suffix_array_equals_cpu"]:
+        sys.exit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gib-per-gpu", type=float, default=4.0)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg3b", "ed64k"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg3b", "ed64k", "sa2m"])
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
@@ -175,6 +218,8 @@ def main():
 
     if args.workload == "ed64k":  # BASELINE config 5 (secondary: the reference's second algorithm)
         return bench_edit_distance(args, dev, local_rank)
+    if args.workload == "sa2m":  # the reference's third program at its largest input size (2 MiB)
+        return bench_suffix_array(args, dev, local_rank)
 
     per_gpu = int(args.gib_per_gpu * (1 << 30))
     base = {"cfg2": corpus.CONFIGS["cfg2_4GiB_m16"], "cfg3": corpus.CONFIGS["cfg3_4GiB_m64_acgt"],

@@ -18,6 +18,8 @@
  *   bmx_search_ranges     kernel1.cl:1 `search(A,B,se,ans,gstable,bstable,sublength)` with the
  *                         launch of BoyreMoore.cpp:264-286: same seven arguments, same per-range
  *                         counts in ans[]
+ *   bmx_edit_distance     EditDistance-1/EditDistance-1/EditDistance-1.cpp:278-345 + kernal.cl:5-56 (second program)
+ *   bmx_suffix_array      SuffixArrays/SuffixArrays/SuffixArrays.cpp:101-154, :417-470 + kernel.cl (third program)
  *   bmx_search_device     the same scan on a text already resident in HBM (the reference re-uploads
  *                         per iteration, BoyreMoore.cpp:246; its timer also starts after the upload, :258)
  *
@@ -179,6 +181,21 @@ int bmx_edit_distance_device(bmx_ctx *ctx, const void *d_a, uint64_t la, const v
 float bmx_last_edit_distance_ms(bmx_ctx *ctx);
 /* Tile shape for experiments: 0 = default (256 rows x 256 columns per wave). */
 int bmx_set_ed_variant(bmx_ctx *ctx, int variant);
+
+/* ---- suffix array: the reference's third program -------------------- */
+
+/* sa[j] = start of the j-th suffix of text[0..n), n < 2^31, in the order the reference's
+ * buildSuffixArray produces (SuffixArrays/SuffixArrays/SuffixArrays.cpp:101-154; its GPU path is
+ * :417-470 with kernel.cl).  That is the ordinary suffix array for the reference's domain
+ * (lower-case text); outside it one quirk of the reference is kept: in the first round "past the
+ * end" ranks like character 96, so the one-character suffix text[n-1] sorts after suffixes whose
+ * second character is below 'a'.  (A text ending in two or more characters 96 leaves suffixes
+ * tied in the reference itself; their mutual order is then unspecified.) */
+int bmx_suffix_array(bmx_ctx *ctx, const char *text, uint64_t n, int32_t *sa);
+int bmx_suffix_array_device(bmx_ctx *ctx, const void *d_text, uint64_t n, int32_t *d_sa, void *stream);
+/* Device time (ms) and number of doubling rounds of the last call. */
+float bmx_last_suffix_array_ms(bmx_ctx *ctx);
+int bmx_last_suffix_array_rounds(bmx_ctx *ctx);
 
 /* ---- synthetic corpus, generated in HBM ---------------------- */
 

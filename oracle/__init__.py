@@ -123,6 +123,8 @@ class Port(_Checker):
         L.bmo_splitmix64.restype = C.c_uint64
         L.edo_edit_distance.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         L.edo_edit_distance.restype = C.c_int64
+        L.sao_suffix_array.argtypes = [C.c_void_p, C.c_int32, _i32p]
+        L.sao_suffix_array.restype = C.c_int
         self.lib = L
         self._build = L.bmo_build_tables
         self._scan = L.bmo_scan
@@ -160,6 +162,14 @@ class Port(_Checker):
             raise MemoryError("edo_edit_distance")
         return d
 
+    def suffix_array(self, text) -> np.ndarray:
+        """Suffix array by prefix doubling (restatement of the reference's buildSuffixArray)."""
+        pt, n, keep = _text_ptr(text)
+        sa = np.empty(max(n, 1), dtype=np.int32)
+        if self.lib.sao_suffix_array(pt, n, sa.ctypes.data_as(_i32p)) != 0:
+            raise MemoryError("sao_suffix_array")
+        return sa[:n].copy()
+
     def gen_text(self, start: int, length: int, seed: int, kind: int = 0) -> np.ndarray:
         out = np.empty(length, dtype=np.uint8)
         self.lib.bmo_gen_text(out.ctypes.data_as(C.c_void_p), start, length, seed & (2**64 - 1), kind)
@@ -181,6 +191,8 @@ class Reference(_Checker):
         L.bmref_scan_ranges.restype = C.c_int
         L.bmref_edit_distance.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         L.bmref_edit_distance.restype = C.c_int64
+        L.bmref_suffix_array.argtypes = [C.c_void_p, C.c_int32, _i32p]
+        L.bmref_suffix_array.restype = C.c_int
         self.lib = L
         self._build = L.bmref_build_tables
         # the reference kernel takes (gstable, bstable) in that order; keep one calling shape
@@ -194,6 +206,13 @@ class Reference(_Checker):
         if d < 0:
             raise ValueError("reference editDistDP: strings too long for its full table")
         return d
+
+    def suffix_array(self, text) -> np.ndarray:
+        """The reference's own buildSuffixArray (SuffixArrays.cpp:101-154)."""
+        pt, n, keep = _text_ptr(text)
+        sa = np.empty(max(n, 1), dtype=np.int32)
+        self.lib.bmref_suffix_array(pt, n, sa.ctypes.data_as(_i32p))
+        return sa[:n].copy()
 
     def scan_ranges(self, text, pattern, ranges):
         """Per-range counts and the hit offsets in kernel call order."""

@@ -26,6 +26,9 @@ static_assert(bmx::MAX_PATTERN == BMX_MAX_PATTERN, "header and kernel disagree")
 
 // bmx_sort.hip
 int bmx_internal_radix_sort(uint64_t *d_keys, uint64_t n, hipStream_t stream, char *err, size_t errlen);
+// bmx_sa.hip
+int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, hipStream_t stream, float *ms_out,
+                              int *rounds_out, char *err, size_t errlen);
 
 namespace {
 
@@ -111,6 +114,8 @@ struct bmx_ctx {
     int last_variant = 0;    // what the most recent search ran (bmx_scan_geometry reports it)
     int ed_variant = 0;      // edit-distance tile shape (bmx_set_ed_variant)
     float ed_last_ms = -1.0f;
+    float sa_last_ms = -1.0f;
+    int sa_last_rounds = 0;
     int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
     unsigned long long *d_count = nullptr; // live match counter; re-armed by order_kernel
     uint32_t *d_bucket_cnt = nullptr;      // ORDER_BUCKETS, re-armed by order_kernel
@@ -605,6 +610,45 @@ int bmx_edit_distance(bmx_ctx *ctx_in, const char *a, uint64_t la, const char *b
     if (!ctx_in) bmx_ctx_destroy(ctx);
     return rc;
 }
+
+// ---- suffix array -------------------------------------------------------
+int bmx_suffix_array_device(bmx_ctx *ctx, const void *d_text, uint64_t n, int32_t *d_sa, void *stream_v)
+{
+    if (!ctx || (n > 0 && (!d_text || !d_sa)) || n >= (1ull << 31)) return BMX_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    return bmx_internal_suffix_array((const uint8_t *)d_text, (uint32_t)n, d_sa, (hipStream_t)stream_v, &ctx->sa_last_ms,
+                                     &ctx->sa_last_rounds, g_err, sizeof g_err);
+}
+
+int bmx_suffix_array(bmx_ctx *ctx_in, const char *text, uint64_t n, int32_t *sa_out)
+{
+    if ((n > 0 && (!text || !sa_out)) || n >= (1ull << 31)) return BMX_ERR_ARG;
+    if (n == 0) return BMX_OK;
+    bmx_ctx *ctx = ctx_in;
+    if (!ctx) {
+        int rc = bmx_ctx_create(0, &ctx);
+        if (rc != BMX_OK) return rc;
+    }
+    void *d_text = nullptr;
+    int32_t *d_sa = nullptr;
+    int rc = bmx_text_upload(ctx, text, n, &d_text);
+    if (rc == BMX_OK) rc = bmx_device_alloc(ctx, n * sizeof(int32_t), (void **)&d_sa);
+    if (rc == BMX_OK) rc = bmx_suffix_array_device(ctx, d_text, n, d_sa, nullptr);
+    if (rc == BMX_OK) {
+        hipError_t e = hipMemcpy(sa_out, d_sa, n * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_err("download of the suffix array: %s", hipGetErrorString(e));
+            rc = BMX_ERR_HIP;
+        }
+    }
+    if (d_sa) (void)hipFree(d_sa);
+    if (d_text) (void)hipFree(d_text);
+    if (!ctx_in) bmx_ctx_destroy(ctx);
+    return rc;
+}
+
+float bmx_last_suffix_array_ms(bmx_ctx *ctx) { return ctx ? ctx->sa_last_ms : -1.0f; }
+int bmx_last_suffix_array_rounds(bmx_ctx *ctx) { return ctx ? ctx->sa_last_rounds : 0; }
 
 int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out)
 {

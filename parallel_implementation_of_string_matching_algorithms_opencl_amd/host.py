@@ -70,6 +70,10 @@ SYMBOLS = [
                                            C.c_void_p]),
     ("bmx_last_edit_distance_ms", C.c_float, [C.c_void_p]),
     ("bmx_set_ed_variant", C.c_int, [C.c_void_p, C.c_int]),
+    ("bmx_suffix_array", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, _i32p]),
+    ("bmx_suffix_array_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    ("bmx_last_suffix_array_ms", C.c_float, [C.c_void_p]),
+    ("bmx_last_suffix_array_rounds", C.c_int, [C.c_void_p]),
     ("bmx_gen_text_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]),
     ("bmx_plant_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int32, _u64p,
                                    C.c_uint64, C.c_void_p]),
@@ -328,6 +332,30 @@ class Context:
 
     def set_ed_variant(self, v: int):
         _check(lib().bmx_set_ed_variant(self._h, v), "bmx_set_ed_variant")
+
+    # -- suffix array (the reference's third program) -----------------------------
+    def suffix_array(self, text) -> np.ndarray:
+        """int32 suffix array in the reference's order (SuffixArrays.cpp:101-154)."""
+        pt, n, keep = _host_text(text)
+        sa = np.empty(max(n, 1), dtype=np.int32)
+        _check(lib().bmx_suffix_array(self._h, pt, n, sa.ctypes.data_as(_i32p)), "bmx_suffix_array")
+        return sa[:n].copy()
+
+    def suffix_array_device(self, d_text):
+        import torch
+
+        n = d_text.numel()
+        d_sa = torch.empty(max(n, 1), dtype=torch.int32, device=d_text.device)
+        stream = C.c_void_p(torch.cuda.current_stream(d_text.device).cuda_stream)
+        _check(lib().bmx_suffix_array_device(self._h, C.c_void_p(d_text.data_ptr()), n, C.c_void_p(d_sa.data_ptr()),
+                                             stream), "bmx_suffix_array_device")
+        return d_sa[:n]
+
+    def last_suffix_array_ms(self) -> float:
+        return float(lib().bmx_last_suffix_array_ms(self._h))
+
+    def last_suffix_array_rounds(self) -> int:
+        return int(lib().bmx_last_suffix_array_rounds(self._h))
 
     # -- synthetic corpus in HBM ------------------------------------------
     def gen_text(self, d_dst, start: int, seed: int, kind: int = 0, length: Optional[int] = None):

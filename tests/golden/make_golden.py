@@ -173,6 +173,29 @@ def main():
     json.dump({"source": "oracle/_ref: the reference's editDistDP (EditDistance-1/EditDistance-1/sequential.c:18-46); "
                          "ED-1 / ED-2 are SURVEY.md s4's known answers (522, 1044)", "cases": ed},
               open(os.path.join(HERE, "edit_distance.json"), "w"))
+    # ---- 7. suffix array (third program): reference buildSuffixArray, SuffixArrays.cpp:101-154 ----
+    sa_cases = []
+    for lit in ["banana", "mississippi", "abracadabra", "aaaaaaaa", "abababab", "a", "zyxwvu", "hello world",
+                "The Quick Brown Fox", "the end."]:
+        sa_cases.append({"text": lit, "sa": ref.suffix_array(lit).tolist()})
+    for _ in range(200):
+        n = int(rng.integers(1, 300))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:  # the reference's domain: lower-case letters
+            t = "".join(chr(97 + int(c)) for c in rng.integers(0, int(rng.integers(1, 27)), n))
+        elif kind == 1:  # small alphabet, long repeats
+            t = "".join("ab"[int(c)] for c in rng.integers(0, 2, n))
+        else:  # printable ASCII without character 96 (ties in the reference, see bmx.h)
+            t = "".join(chr(int(c) if int(c) != 96 else 95) for c in rng.integers(32, 127, n))
+        sa_cases.append({"text": t, "sa": ref.suffix_array(t).tolist()})
+    for stored in ("input5L.txt.gz", "input7.txt"):
+        path = os.path.join(data_dir, stored)
+        raw = gzip.open(path, "rb").read() if stored.endswith(".gz") else open(path, "rb").read()
+        sa = ref.suffix_array(raw)
+        sa_cases.append({"file": stored, "bytes": len(raw), "sha256": sha(sa), "first": sa[:8].tolist(),
+                         "last": sa[-8:].tolist()})
+    json.dump({"source": "oracle/_ref: the reference's buildSuffixArray (SuffixArrays/SuffixArrays/SuffixArrays.cpp:"
+                         "101-154)", "cases": sa_cases}, open(os.path.join(HERE, "suffix_array.json"), "w"))
     print("golden fixtures written:", sorted(os.listdir(HERE)))
 
 
