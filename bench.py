@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the N > 1 code path (RCCL process group, slot all-gather, merge) even with one rank: "
+                         "a 1-GPU check of the calls the 2/4/8-GPU runs make")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on cuda:0 with the exchange staged through host memory on gloo "
                          "(RCCL refuses duplicate devices): exercises the multi-rank code path on a 1-GPU box; "
@@ -203,14 +206,18 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
                   file=sys.stderr)
         sys.exit(2)
+    multi = world > 1 or args.force_exchange  # take the distributed code path
     rehearse = args.rehearse_on_one_gpu and world > 1
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearse else dev  # where the small control collectives live
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -238,7 +245,7 @@ def main():
     tables = host.build_tables(pat)  # host tables once, like BoyreMoore.cpp:150-190 (outside its timer too)
 
     state = {}
-    if world > 1:
+    if multi:
         xchg = shard.SlotExchange(ctx, world, rank, dev, slot=SLOT, via_host=rehearse)  # [count | offsets...] over RCCL
         out = xchg.out
     else:
@@ -247,14 +254,14 @@ def main():
     query = ctx.prepare(d_text, pat, out, n=length, n_own=n_own, base_offset=start, tables=tables)
 
     def step():
-        if world > 1:
+        if multi:
             state["result"] = xchg.run(query)  # scan + order + all-gather + merge; one stream sync
         else:
             query.enqueue()
             state["result"] = out[:query.finish()]  # the step's one host wait (polls the pinned status word)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -266,7 +273,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -283,7 +290,7 @@ def main():
     # HIP events recorded around every scan kernel of the timed region (ring of 64), read afterwards
     scan_ms = ctx.scan_ms_history(min(args.steps, 64))
     avg_scan_ms = float(np.mean(scan_ms))
-    if world > 1:  # roofline of the slowest rank's kernel
+    if multi:  # roofline of the slowest rank's kernel
         t = torch.tensor([avg_scan_ms], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         avg_scan_ms = float(t.item())
@@ -299,7 +306,7 @@ def main():
                    "pattern_bytes": m, "alphabet": "printable-95" if spec.kind == 0 else "ACGT",
                    "matches": int(result.size), "sharding": f"{world} contiguous shard(s) + {m - 1} B halo",
                    "exchange": ("REHEARSAL on one GPU, gloo via host" if rehearse else
-                                "RCCL all-gather of [count|offsets] slots") if world > 1 else "none",
+                                "RCCL all-gather of [count|offsets] slots") if multi else "none",
                    "kernel": f"{geom['kind']} block {geom['block']} seg {geom['seg']} grid {geom['grid']} "
                              f"lds {geom['lds_bytes']}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -323,7 +330,7 @@ def main():
     ok = planted_ok and all(v is not False for v in line["parity"].values())
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

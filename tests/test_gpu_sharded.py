@@ -51,6 +51,52 @@ def _worker(rank, world, port, spec_args, slot, q):
         dist.destroy_process_group()
 
 
+def _worker_rccl(port, spec_args, q):
+    """World of ONE rank on the real RCCL backend: the collective call itself
+    (all_gather_into_tensor on device tensors), the merge kernel and the pinned-memory poll."""
+    import torch
+    import torch.distributed as dist
+
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus, host, shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        spec = corpus.CorpusSpec(*spec_args)
+        ctx = host.Context(0)
+        d_text = spec.device_text(ctx, device=dev)
+        xchg = shard.SlotExchange(ctx, 1, 0, dev, slot=8192)  # via_host=False: RCCL
+        query = ctx.prepare(d_text, spec.pattern(), xchg.out, tables=host.build_tables(spec.pattern()))
+        for _ in range(3):
+            res = xchg.run(query)
+        q.put(res.cpu().numpy().astype(np.uint64))
+        dist.barrier()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slot_exchange_on_rccl_with_one_rank(port, ctx):
+    import torch.multiprocessing as mp
+
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus
+
+    spec_args = ("rccl1", 8 * (1 << 20) + 5, 16, 0, 0x5EED0004, 1 << 16, 1 << 20, -1)
+    spec = corpus.CorpusSpec(*spec_args)
+    want = port.search(spec.host_text(), spec.pattern())
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    p = mpc.Process(target=_worker_rccl, args=(_free_port(), spec_args, q))
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=300)
+    assert p.exitcode == 0
+    assert np.array_equal(got, want)
+
+
 def _run(world, spec_args, slot):
     import torch.multiprocessing as mp
 
@@ -114,3 +160,23 @@ def test_bench_multi_rank_path_rehearsal(ctx):
     assert line["parity"]["planted_offsets_exact"] is True
     assert line["config"]["text_bytes_total"] == 2 * line["config"]["text_bytes_per_gpu"]
     assert line["config"]["matches"] > 500 and line["roofline"]["bound"] == "hbm"
+
+
+def test_bench_distributed_path_on_rccl_with_one_rank(ctx):
+    """bench.py --force-exchange: the N > 1 branch (RCCL process group bound to the device, slot
+    all-gather, merge, barrier, MAX all-reduce of the timings) with the one rank a 1-GPU box allows."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+           "--gib-per-gpu", "0.25", "--force-exchange", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["exchange"].startswith("RCCL")
+    assert line["parity"]["planted_offsets_exact"] is True and line["config"]["matches"] > 100
