@@ -15,6 +15,8 @@
  *                                                  clEnqueueReadBuffer -- as ONE call that returns
  *                                                  the match positions the kernel only printf()s
  *                                                  (BoyreMoore/x64/Debug/kernel1.cl:24)
+ *   bmx_search_multi      the same, with the text cut over several GPUs (stands where the
+ *                         reference cuts it over two work-items, BoyreMoore.cpp:94-141, :273)
  *   bmx_search_ranges     kernel1.cl:1 `search(A,B,se,ans,gstable,bstable,sublength)` with the
  *                         launch of BoyreMoore.cpp:264-286: same seven arguments, same per-range
  *                         counts in ans[]
@@ -81,6 +83,21 @@ const char *bmx_version(void);
  * ctx may be NULL (a context on device 0 is created and destroyed inside). */
 int bmx_search(bmx_ctx *ctx, const char *text, uint64_t n, const char *pat, int32_t m,
                uint64_t *match_positions, uint64_t capacity, uint64_t *n_matches);
+
+/* One process driving several GPUs: the text is cut into n_devices contiguous
+ * shards (boundaries on multiples of 16 B, each shard followed by its (m-1)-byte
+ * halo; a hit belongs to the shard holding its first byte), shard d is uploaded to
+ * and scanned on devices[d] by its own host thread with its own context and
+ * stream, and the ascending shard lists are concatenated in shard order -- the
+ * global ascending list, identical to bmx_search's.  devices == NULL means
+ * 0 .. n_devices-1; a device may be listed more than once (its shards then share
+ * it).  Replaces the reference's 2-way split of the text at spaces over two
+ * work-items (BoyreMoore.cpp:94-141 + global size 2 at :273), which loses the hits
+ * that straddle the cut.  The one-process-per-GPU form of the same cut, with the
+ * RCCL exchange, is shard.py / bench.py. */
+int bmx_search_multi(const char *text, uint64_t n, const char *pat, int32_t m,
+                     const int32_t *devices, int32_t n_devices, uint64_t *match_positions,
+                     uint64_t capacity, uint64_t *n_matches);
 
 /* Reference kernel contract: P inclusive ranges se[2P] (int, as the reference),
  * ans[P] = hits whose whole window lies inside the range.  Tables are the

@@ -14,6 +14,10 @@
 //                             inclusive ranges like BoyreMoore.cpp:94-141 and
 //                             print the per-range counts of bmx_search_ranges
 //           [--device D]
+//           [--gpus G]        also run the search over G GPUs from this one process
+//                             (bmx_search_multi: G shards, one host thread each) and
+//                             check its list against the one-GPU list
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -70,7 +74,7 @@ std::vector<int32_t> split_like_reference(const std::string &text, int P)
 int main(int argc, char **argv)
 {
     std::string text_path = "inputEd.txt", pat_path = "input1Search.txt";
-    int iters = 10, device = 0, ranges = 0;
+    int iters = 10, device = 0, ranges = 0, gpus = 0;
     bool positions = false;
     uint64_t max_print = 32;
     for (int i = 1; i < argc; ++i) {
@@ -86,6 +90,7 @@ int main(int argc, char **argv)
         else if (a == "--pattern") pat_path = need("--pattern");
         else if (a == "--iters") iters = atoi(need("--iters"));
         else if (a == "--device") device = atoi(need("--device"));
+        else if (a == "--gpus") gpus = atoi(need("--gpus"));
         else if (a == "--ranges") ranges = atoi(need("--ranges"));
         else if (a == "--max-print") max_print = strtoull(need("--max-print"), nullptr, 10);
         else if (a == "--positions") positions = true;
@@ -165,6 +170,25 @@ int main(int argc, char **argv)
     if (iters > 0) {
         const double avg = total / iters;
         printf("Average time = %.6f s  (%.3f GB/s)\n", avg, avg > 0 ? (double)n / avg / 1e9 : 0.0);
+    }
+
+    if (gpus > 0) { // host buffers in and out: upload + scan + download per call, over `gpus` devices
+        std::vector<uint64_t> one(n_matches ? n_matches : 1), many(n_matches ? n_matches : 1);
+        uint64_t got1 = 0, gotN = 0;
+        rc = bmx_search(ctx, text.data(), n, pat.data(), m, one.data(), one.size(), &got1);
+        auto t0 = std::chrono::steady_clock::now();
+        if (rc == BMX_OK)
+            rc = bmx_search_multi(text.data(), n, pat.data(), m, nullptr, gpus, many.data(), many.size(), &gotN);
+        auto t1 = std::chrono::steady_clock::now();
+        if (rc != BMX_OK) {
+            fprintf(stderr, "bmx_search_multi over %d GPUs failed: %d (%s)\n", gpus, rc, bmx_last_error());
+            return 1;
+        }
+        const bool same = got1 == gotN && std::equal(one.begin(), one.begin() + got1, many.begin());
+        printf("%d GPUs, host buffers in and out: %llu occurrences in %.6f s, list %s the one-GPU list\n", gpus,
+               (unsigned long long)gotN, std::chrono::duration<double>(t1 - t0).count(),
+               same ? "identical to" : "DIFFERS from");
+        if (!same) return 1;
     }
 
     // the positions, through the host-buffer entry point (text, pattern, match_positions)

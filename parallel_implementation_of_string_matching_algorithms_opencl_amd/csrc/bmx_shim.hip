@@ -13,6 +13,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "bmx_scan_kernel.h"
@@ -719,6 +721,101 @@ int bmx_search(bmx_ctx *ctx_in, const char *text, uint64_t n, const char *pat, i
     if (d_text) (void)hipFree(d_text);
     if (!ctx_in) bmx_ctx_destroy(ctx);
     return rc;
+}
+
+// One process, several GPUs (SURVEY.md s8b "multi-GPU variant may spawn one host thread per
+// device internally"): contiguous shards with 16-B aligned boundaries and an (m-1)-byte halo,
+// a hit is owned by the shard holding its first byte -- the same cut as shard.py makes for
+// the one-process-per-GPU path -- so the shard lists concatenate into the global ascending list.
+int bmx_search_multi(const char *text, uint64_t n, const char *pat, int32_t m, const int32_t *devices,
+                     int32_t n_devices, uint64_t *match_positions, uint64_t capacity, uint64_t *n_matches)
+{
+    if (!pat || m < 1 || m > BMX_MAX_PATTERN || (n > 0 && !text) || n_devices < 1) return BMX_ERR_ARG;
+    if (capacity > 0 && !match_positions) return BMX_ERR_ARG;
+    if (n_matches) *n_matches = 0;
+    int32_t bad[BMX_BAD_TABLE_SIZE];
+    std::vector<int32_t> good(m);
+    int rc = bmx_build_tables(pat, m, bad, good.data());
+    if (rc != BMX_OK) return rc;
+    const int have = bmx_device_count();
+    for (int d = 0; d < n_devices; ++d) {
+        const int dev = devices ? devices[d] : d;
+        if (dev < 0 || dev >= have) {
+            set_err("bmx_search_multi: no HIP device %d (count %d)", dev, have);
+            return BMX_ERR_NO_DEVICE;
+        }
+    }
+    if (n < (uint64_t)m) return BMX_OK;
+
+    struct Shard {
+        int device = 0;
+        uint64_t lo = 0, len = 0, n_own = 0; // resident bytes [lo, lo + len), window starts [lo, lo + n_own)
+        int rc = BMX_OK;
+        uint64_t total = 0;
+        std::vector<uint64_t> hits;
+        std::string err;
+    };
+    const uint64_t D = (uint64_t)n_devices;
+    uint64_t per = (n + D - 1) / D;
+    per = (per + 15) / 16 * 16;
+    std::vector<Shard> shards(n_devices);
+    for (uint64_t d = 0; d < D; ++d) {
+        Shard &s = shards[d];
+        s.device = devices ? devices[d] : (int)d;
+        s.lo = std::min(n, d * per);
+        const uint64_t hi = std::min(n, (d + 1) * per);
+        s.n_own = hi - s.lo;
+        s.len = std::min(n, hi + (uint64_t)m - 1) - s.lo;
+    }
+    auto work = [&](Shard &s) {
+        if (s.len < (uint64_t)m || s.n_own == 0) return; // no whole window starts here
+        bmx_ctx *ctx = nullptr;
+        void *d_text = nullptr;
+        uint64_t *d_out = nullptr;
+        hipStream_t stream = nullptr;
+        const uint64_t dev_cap = std::min<uint64_t>(capacity, std::min(s.n_own, s.len - (uint64_t)m + 1));
+        s.rc = bmx_ctx_create(s.device, &ctx);
+        if (s.rc == BMX_OK && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+            set_err("bmx_search_multi: stream on device %d", s.device);
+            s.rc = BMX_ERR_HIP;
+        }
+        if (s.rc == BMX_OK) s.rc = bmx_text_upload(ctx, text + s.lo, s.len, &d_text);
+        if (s.rc == BMX_OK && dev_cap) s.rc = bmx_device_alloc(ctx, dev_cap * sizeof(uint64_t), (void **)&d_out);
+        if (s.rc == BMX_OK)
+            s.rc = bmx_search_device(ctx, d_text, s.len, s.n_own, s.lo, pat, m, good.data(), bad, d_out, dev_cap,
+                                     &s.total, stream);
+        if (s.rc == BMX_OK || s.rc == BMX_ERR_CAPACITY) {
+            s.hits.resize(std::min(s.total, dev_cap));
+            if (!s.hits.empty() && hipMemcpy(s.hits.data(), d_out, s.hits.size() * sizeof(uint64_t),
+                                             hipMemcpyDeviceToHost) != hipSuccess) {
+                set_err("bmx_search_multi: download from device %d", s.device);
+                s.rc = BMX_ERR_HIP;
+            }
+        }
+        if (s.rc != BMX_OK) s.err = g_err; // g_err is per thread: hand the text to the caller's thread
+        if (d_out) (void)hipFree(d_out);
+        if (d_text) (void)hipFree(d_text);
+        if (stream) (void)hipStreamDestroy(stream);
+        bmx_ctx_destroy(ctx);
+    };
+    std::vector<std::thread> pool;
+    for (int d = 1; d < n_devices; ++d) pool.emplace_back(work, std::ref(shards[d]));
+    work(shards[0]);
+    for (auto &t : pool) t.join();
+
+    uint64_t total = 0, stored = 0;
+    for (const Shard &s : shards) {
+        if (s.rc != BMX_OK && s.rc != BMX_ERR_CAPACITY) {
+            set_err("%s", s.err.c_str());
+            return s.rc;
+        }
+        total += s.total;
+        const uint64_t take = std::min<uint64_t>(s.hits.size(), capacity - stored);
+        if (take) std::memcpy(match_positions + stored, s.hits.data(), take * sizeof(uint64_t));
+        stored += take;
+    }
+    if (n_matches) *n_matches = total;
+    return total > capacity ? BMX_ERR_CAPACITY : BMX_OK;
 }
 
 int bmx_search_ranges(bmx_ctx *ctx_in, const char *text, uint64_t n, const char *pat, const int32_t *se,

@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -47,6 +47,8 @@ SYMBOLS = [
     ("bmx_last_error", C.c_char_p, []),
     ("bmx_version", C.c_char_p, []),
     ("bmx_search", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int32, _u64p, C.c_uint64, _u64p]),
+    ("bmx_search_multi", C.c_int, [C.c_void_p, C.c_uint64, C.c_char_p, C.c_int32, _i32p, C.c_int32, _u64p, C.c_uint64,
+                                   _u64p]),
     ("bmx_search_ranges", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, _i32p, C.c_int32, _i32p,
                                     _i32p, _i32p, C.c_int32]),
     ("bmx_search_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p,
@@ -428,6 +430,30 @@ def default_context() -> Context:
 def search(text, pattern) -> np.ndarray:
     """(text, pattern) -> match_positions, the north-star entry point."""
     return default_context().search(text, pattern)
+
+
+def search_multi(text, pattern, devices: Union[int, Sequence[int]], capacity: Optional[int] = None) -> np.ndarray:
+    """One process, several GPUs (bmx_search_multi): ``devices`` is a count (devices
+    0..count-1) or an explicit list, one contiguous shard of the text per entry."""
+    pat = _pat_bytes(pattern)
+    tptr, n, keep = _host_text(text)
+    m = len(pat)
+    if isinstance(devices, int):
+        dptr, nd = None, devices
+    else:
+        darr = np.ascontiguousarray(devices, dtype=np.int32)
+        dptr, nd = darr.ctypes.data_as(_i32p), int(darr.size)
+    cap = capacity if capacity is not None else max(1, min(max(n - m + 1, 1), 1 << 20))
+    while True:
+        out = np.empty(max(cap, 1), dtype=np.uint64)
+        total = C.c_uint64(0)
+        rc = lib().bmx_search_multi(tptr, n, pat, m, dptr, nd, out.ctypes.data_as(_u64p), cap, C.byref(total))
+        if rc == ERR_CAPACITY and capacity is None:
+            cap = int(total.value)
+            continue
+        _check(rc, "bmx_search_multi")
+        del keep
+        return out[: int(total.value)].copy()
 
 
 def search_ranges(text, pattern, ranges, tables=None) -> np.ndarray:

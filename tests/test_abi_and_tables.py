@@ -101,6 +101,21 @@ def test_argument_errors_without_device_work(built):
     assert L.bmx_search(None, C.cast(buf, C.c_void_p), 2, b"\xff", 1, None, 0, None) == host.ERR_DOMAIN
 
 
+def test_multi_gpu_entry_point_argument_errors(built):
+    L = host.lib()
+    buf = C.create_string_buffer(b"abcabcabc")
+    t = C.cast(buf, C.c_void_p)
+    total = C.c_uint64(7)
+    assert L.bmx_search_multi(None, 9, b"abc", 3, None, 1, None, 0, None) == host.ERR_ARG  # NULL text
+    assert L.bmx_search_multi(t, 9, b"abc", 3, None, 0, None, 0, None) == host.ERR_ARG  # no devices
+    assert L.bmx_search_multi(t, 9, b"", 0, None, 1, None, 0, None) == host.ERR_ARG  # m < 1
+    assert L.bmx_search_multi(t, 9, b"\xff", 1, None, 1, None, 0, None) == host.ERR_DOMAIN
+    bad_dev = (C.c_int32 * 2)(0, 1 << 20)
+    assert L.bmx_search_multi(t, 9, b"abc", 3, bad_dev, 2, None, 0, C.byref(total)) == host.ERR_NO_DEVICE
+    assert total.value == 0
+    assert b"device" in L.bmx_last_error()
+
+
 def test_no_cpu_fallback_without_gpu(built):
     import torch
 
@@ -108,4 +123,7 @@ def test_no_cpu_fallback_without_gpu(built):
         pytest.skip("GPU present")
     with pytest.raises(host.BmxError) as e:
         host.Context(0)
+    assert e.value.rc == host.ERR_NO_DEVICE
+    with pytest.raises(host.BmxError) as e:  # the several-GPU entry point does not fall back either
+        host.search_multi(b"abcabc", b"abc", 1)
     assert e.value.rc == host.ERR_NO_DEVICE

@@ -306,6 +306,32 @@ def test_shard_decomposition_equals_unsharded(ctx, port):
         assert np.array_equal(shard.merge_shard_lists(lists), want), world
 
 
+def test_one_process_several_gpus_entry_point(ctx, port):
+    """bmx_search_multi: host threads, one shard each.  The box has one GPU, so the device
+    list names it several times -- the cut, the halo, ownership, global offsets, the per-thread
+    contexts running at the same time and the concatenation are what 8 GPUs would run."""
+    spec = corpus.CorpusSpec("multi", 5 * (1 << 20) + 333, 16, 0, 0x5EED0004, 1 << 16, 1 << 18, -1)
+    text = spec.host_text()
+    want = port.search(text, spec.pattern())
+    assert want.size > 50
+    for devices in (1, [0], [0, 0], [0, 0, 0], [0] * 8):
+        assert np.array_equal(host.search_multi(text, spec.pattern(), devices), want), devices
+    rng = np.random.default_rng(77)
+    for _ in range(12):  # small alphabets: overlapping hits, hits across every cut, short last shards
+        n = int(rng.integers(1, 4000))
+        t = rng.integers(97, 99, size=n, dtype=np.uint8)
+        pat = bytes(rng.integers(97, 99, size=int(rng.integers(1, 9)), dtype=np.uint8))
+        world = int(rng.integers(1, 7))
+        assert np.array_equal(host.search_multi(t, pat, [0] * world), port.search(t, pat)), (n, pat, world)
+    # capacity: the true total comes back with the error, like bmx_search
+    with pytest.raises(host.BmxError) as e:
+        host.search_multi(text, spec.pattern(), [0, 0], capacity=10)
+    assert e.value.rc == host.ERR_CAPACITY
+    with pytest.raises(host.BmxError) as e:
+        host.search_multi(text, spec.pattern(), [0, 99])
+    assert e.value.rc == host.ERR_NO_DEVICE
+
+
 # ---------------------------------------------------------------- BASELINE full sizes
 @pytest.mark.parametrize("name", ["cfg2_4GiB_m16", "cfg3_4GiB_m64_acgt", "cfg3b_4GiB_m64_p95"])
 def test_full_size_configs_find_exactly_the_planted_offsets(ctx, port, name):
@@ -379,9 +405,10 @@ def test_cpp_driver_on_a_reference_corpus_file(ctx, tmp_path):
     raw = golden_file_bytes("input5L.txt.gz")
     (tmp_path / "inputEd.txt").write_bytes(raw)
     (tmp_path / "input1Search.txt").write_bytes(b"occurrences")
-    r = subprocess.run([exe, "--iters", "3", "--positions", "--max-print", "2", "--ranges", "2"], cwd=tmp_path,
+    r = subprocess.run([exe, "--iters", "3", "--positions", "--max-print", "2", "--ranges", "2", "--gpus", "1"], cwd=tmp_path,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "occurrences: 1098" in r.stdout
     assert "Found at : 37" in r.stdout
     assert "Average time" in r.stdout and "process 1 is" in r.stdout
+    assert "1 GPUs, host buffers in and out: 1098 occurrences" in r.stdout and "identical to" in r.stdout
