@@ -515,25 +515,27 @@ int bmx_scan_stamps(bmx_ctx *ctx, uint64_t *out, uint64_t max_words)
 namespace {
 struct EdVariant {
     int c, r;
-    void (*kernel)(const bmx::EdArgs);
+    void (*kernel)(const bmx::EdArgs); // one tile diagonal per launch, from the top-left corner
+    void (*dual)(const bmx::EdArgs);   // a forward and a mirrored tile diagonal per launch (nullptr: none)
 };
-#define BMX_ED(C_, R_, LEAN_) {C_, R_, bmx::ed_tile_kernel<C_, R_, LEAN_>}
+#define BMX_ED(C_, R_) {C_, R_, bmx::ed_tile_kernel<C_, R_, true>, bmx::ed_dual_kernel<C_, R_>}
 const EdVariant g_ed_variants[] = {
-    BMX_ED(4, 256, true),  // 0: default: tiles of 256 rows x 256 columns, lean step
-    BMX_ED(4, 128, true),  // 1
-    BMX_ED(8, 256, true),  // 2
-    BMX_ED(4, 384, true),  // 3
-    BMX_ED(6, 256, true),  // 4
-    BMX_ED(4, 256, false), // 5: the first version (ds_bpermute shuffle, predicated steps)
-    BMX_ED(4, 512, true),  // 6
-    BMX_ED(3, 256, true),  // 7
+    BMX_ED(4, 256), // 0: default: tiles of 256 rows x 256 columns, lean step
+    BMX_ED(4, 128), // 1
+    BMX_ED(8, 256), // 2
+    BMX_ED(4, 384), // 3
+    BMX_ED(6, 256), // 4
+    {4, 256, bmx::ed_tile_kernel<4, 256, false>, nullptr}, // 5: the first version (ds_bpermute shuffle, predicated steps)
+    BMX_ED(4, 512), // 6
+    BMX_ED(3, 256), // 7
 };
 constexpr int N_ED_VARIANTS = sizeof(g_ed_variants) / sizeof(g_ed_variants[0]);
+constexpr int ED_ONE_DIRECTION = 16; // flag on the variant number: do not meet in the middle
 } // namespace
 
 int bmx_set_ed_variant(bmx_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || variant >= N_ED_VARIANTS) return BMX_ERR_ARG;
+    if (!ctx || variant < 0 || (variant & ~ED_ONE_DIRECTION) >= N_ED_VARIANTS) return BMX_ERR_ARG;
     ctx->ed_variant = variant;
     return BMX_OK;
 }
@@ -552,30 +554,66 @@ int bmx_edit_distance_device(bmx_ctx *ctx, const void *d_a, uint64_t la, const v
     }
     hipStream_t stream = (hipStream_t)stream_v;
     HIPCHK(hipSetDevice(ctx->device));
-    const EdVariant &v = g_ed_variants[ctx->ed_variant];
+    const EdVariant &v = g_ed_variants[ctx->ed_variant & ~ED_ONE_DIRECTION];
     const uint32_t W = 64u * v.c, R = (uint32_t)v.r;
-    bmx::EdArgs a;
+    bmx::EdArgs a = {};
     a.a = (const uint8_t *)d_a;
     a.b = (const uint8_t *)d_b;
     a.la = (uint32_t)la;
     a.lb = (uint32_t)lb;
     a.tile_cols = (a.la + W - 1) / W;
     a.tile_rows = (a.lb + R - 1) / R;
-    uint32_t *ws = nullptr; // [3 x (la+1) bottom rows | lb+1 right column | result]
-    const uint64_t words = 3 * (la + 1) + (lb + 1) + 1;
+    const uint32_t ndiag = a.tile_rows + a.tile_cols - 1;
+    // Two-ended schedule: forward tile diagonals 0..K, mirrored ones for the rest, pairwise in one
+    // launch; worth it as soon as there are three diagonals.
+    const bool two_ended = v.dual && !(ctx->ed_variant & ED_ONE_DIRECTION) && ndiag >= 3;
+    const uint64_t n_srow = (uint64_t)a.tile_cols * (W + 1), n_scol = (uint64_t)a.tile_rows * (R + 1);
+    // [3 x (la+1) bottom rows | lb+1 right column] per direction | staircase F/G rows, F/G columns | result
+    const uint64_t per_dir = 3 * (la + 1) + (lb + 1);
+    const uint64_t words = (two_ended ? 2 * per_dir + 2 * n_srow + 2 * n_scol : per_dir) + 1;
+    uint32_t *ws = nullptr;
     HIPCHK(hipMalloc(&ws, words * sizeof(uint32_t)));
     a.bottom = ws;
     a.rightcol = ws + 3 * (la + 1);
-    a.result = a.rightcol + (lb + 1);
+    a.result = ws + words - 1;
     const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING); // borrow an event pair, outside the scan history
     hipError_t e = hipEventRecord(ctx->ev0[slot], stream);
-    const uint32_t ndiag = a.tile_rows + a.tile_cols - 1;
-    for (uint32_t d = 0; d < ndiag && e == hipSuccess; ++d) {
+    auto blocks_on = [&](uint32_t d) { // tiles on (logical) tile diagonal d
         const uint32_t i_lo = d >= a.tile_cols ? d - (a.tile_cols - 1) : 0;
-        const uint32_t i_hi = std::min(d, a.tile_rows - 1);
-        a.diag = d;
-        hipLaunchKernelGGL(v.kernel, dim3(i_hi - i_lo + 1), dim3(64), 0, stream, a);
-        e = hipGetLastError();
+        return std::min(d, a.tile_rows - 1) - i_lo + 1;
+    };
+    if (!two_ended) {
+        for (uint32_t d = 0; d < ndiag && e == hipSuccess; ++d) {
+            a.diag = d;
+            hipLaunchKernelGGL(v.kernel, dim3(blocks_on(d)), dim3(64), 0, stream, a);
+            e = hipGetLastError();
+        }
+    } else {
+        a.bottom_m = ws + per_dir;
+        a.rightcol_m = a.bottom_m + 3 * (la + 1);
+        uint32_t *stair = ws + 2 * per_dir;
+        a.stair_row[0] = stair;
+        a.stair_row[1] = stair + n_srow;
+        a.stair_col[0] = stair + 2 * n_srow;
+        a.stair_col[1] = stair + 2 * n_srow + n_scol;
+        if (e == hipSuccess) // 0xFF.. = bmx::ED_NONE: edges only one direction reaches never pair up
+            e = hipMemsetAsync(stair, 0xFF, (2 * n_srow + 2 * n_scol) * sizeof(uint32_t), stream);
+        const uint32_t K = (ndiag - 2) / 2;     // forward: diagonals 0..K
+        const uint32_t last_m = ndiag - 2 - K;  // mirrored: its own diagonals 0..last_m (= table diagonals ndiag-1 .. K+1)
+        for (uint32_t t = 0; t <= std::max(K, last_m) && e == hipSuccess; ++t) {
+            const uint32_t nf = t <= K ? blocks_on(t) : 0, nm = t <= last_m ? blocks_on(t) : 0;
+            a.diag = a.diag_m = t;
+            a.n_fwd = nf;
+            a.stair_fwd = t == K;
+            a.stair_m = t == last_m;
+            hipLaunchKernelGGL(v.dual, dim3(nf + nm), dim3(64), 0, stream, a);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(bmx::ed_meet_kernel, dim3(1), dim3(1024), 0, stream, a.stair_row[0], a.stair_row[1],
+                               (uint32_t)n_srow, a.stair_col[0], a.stair_col[1], (uint32_t)n_scol, a.result);
+            e = hipGetLastError();
+        }
     }
     uint32_t h_result = 0;
     if (e == hipSuccess) e = hipEventRecord(ctx->ev1[slot], stream);

@@ -68,7 +68,9 @@ def test_gpu_vs_oracle_around_tile_edges_all_tile_shapes(ctx, port):
     rng = np.random.default_rng(7)
     lens = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 1025]
     try:
-        for v in range(6):
+        # 0..5: tile shapes, filled from both corners at once where there are three tile
+        # diagonals or more; +16: the same shapes filled from the top-left corner only
+        for v in [0, 1, 2, 3, 4, 5, 16, 17, 18, 20]:
             ctx.set_ed_variant(v)
             for _ in range(14):
                 la, lb = int(rng.choice(lens)), int(rng.choice(lens))
@@ -76,6 +78,35 @@ def test_gpu_vs_oracle_around_tile_edges_all_tile_shapes(ctx, port):
                 x = (rng.integers(0, al, la) + 97).astype(np.uint8)
                 y = (rng.integers(0, al, lb) + 97).astype(np.uint8)
                 assert ctx.edit_distance(x, y) == port.edit_distance(x, y), (v, la, lb)
+    finally:
+        ctx.set_ed_variant(0)
+
+
+@pytest.mark.gpu
+def test_gpu_two_ended_schedule_on_every_grid_shape(ctx, port):
+    """The forward and the mirrored half meet on a staircase of tile edges: grids of 1..9 x
+    1..9 tiles (128 x 256 tiles, variant 1), full and ragged last tiles, strings that are
+    related (long shared runs: the optimal path hugs the diagonal) and unrelated."""
+    rng = np.random.default_rng(11)
+    ctx.set_ed_variant(1)
+    try:
+        for tr in (1, 2, 3, 5, 9):
+            for tc in (1, 2, 3, 4, 7):
+                for ragged in (False, True):
+                    lb = tr * 128 - (int(rng.integers(1, 128)) if ragged else 0)
+                    la = tc * 256 - (int(rng.integers(1, 256)) if ragged else 0)
+                    x = (rng.integers(0, 3, la) + 97).astype(np.uint8)
+                    if rng.integers(0, 2):  # related: y is an edited copy of x, cut or padded to lb
+                        y = x.copy()
+                        y[rng.integers(0, la, la // 9 + 1)] = ord("z")
+                        y = np.delete(y, rng.integers(0, la, la // 17 + 1))
+                        y = np.resize(y, lb) if y.size >= lb else np.concatenate(
+                            [y, (rng.integers(0, 3, lb - y.size) + 97).astype(np.uint8)])
+                    else:
+                        y = (rng.integers(0, 3, lb) + 97).astype(np.uint8)
+                    want = port.edit_distance(x, y)
+                    assert ctx.edit_distance(x, y) == want, (tr, tc, la, lb)
+                    assert ctx.edit_distance(y, x) == want, (tc, tr, lb, la)
     finally:
         ctx.set_ed_variant(0)
 
@@ -123,4 +154,9 @@ def test_gpu_config5_64k_properties(ctx, port):
     dz = torch.from_numpy(z).cuda()
     d1 = ctx.edit_distance_device(dx, dz)
     assert d1 == ctx.edit_distance_device(dz, dx)
+    ctx.set_ed_variant(16)  # one direction only: the schedule of the first version
+    try:
+        assert d1 == ctx.edit_distance_device(dx, dz)
+    finally:
+        ctx.set_ed_variant(0)
     assert d1 == port.edit_distance(x, z)
