@@ -196,8 +196,9 @@ int bmx_edit_distance_device(bmx_ctx *ctx, const void *d_a, uint64_t la, const v
                              uint64_t *distance, void *stream);
 /* Device time (ms, HIP events around all tile-diagonal launches) of the last call. */
 float bmx_last_edit_distance_ms(bmx_ctx *ctx);
-/* Tile shape for experiments: 0 = default (256 rows x 256 columns per wave); +16 = fill the
- * table from the top-left corner only instead of from both corners at once. */
+/* Kernel shape for experiments: 0 = default (4 columns per lane = 256 per wave; one launch, a
+ * pipeline of column bands from both corners); +32 = one launch per pair of tile diagonals from
+ * both corners; +16 = one launch per tile diagonal from the top-left corner only. */
 int bmx_set_ed_variant(bmx_ctx *ctx, int variant);
 
 /* ---- suffix array: the reference's third program -------------------- */

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -20,6 +21,7 @@
 #include "bmx_scan_kernel.h"
 
 #include "bmx_aux_kernels.h"
+#include "bmx_ed_band_kernel.h"
 #include "bmx_ed_kernel.h"
 #include "bmx_scan_ring_kernel.h"
 #include "bmx_scan_wave_kernel.h"
@@ -515,27 +517,110 @@ int bmx_scan_stamps(bmx_ctx *ctx, uint64_t *out, uint64_t max_words)
 namespace {
 struct EdVariant {
     int c, r;
-    void (*kernel)(const bmx::EdArgs); // one tile diagonal per launch, from the top-left corner
-    void (*dual)(const bmx::EdArgs);   // a forward and a mirrored tile diagonal per launch (nullptr: none)
+    void (*kernel)(const bmx::EdArgs);   // one tile diagonal per launch, from the top-left corner
+    void (*dual)(const bmx::EdArgs);     // a forward and a mirrored tile diagonal per launch (nullptr: none)
+    void (*band)(const bmx::EdBandArgs); // the whole table in one launch: pipeline of column bands, both directions
 };
-#define BMX_ED(C_, R_) {C_, R_, bmx::ed_tile_kernel<C_, R_, true>, bmx::ed_dual_kernel<C_, R_>}
+#define BMX_ED(C_, R_) {C_, R_, bmx::ed_tile_kernel<C_, R_, true>, bmx::ed_dual_kernel<C_, R_>, bmx::ed_band_kernel<C_>}
 const EdVariant g_ed_variants[] = {
     BMX_ED(4, 256), // 0: default: tiles of 256 rows x 256 columns, lean step
     BMX_ED(4, 128), // 1
     BMX_ED(8, 256), // 2
     BMX_ED(4, 384), // 3
     BMX_ED(6, 256), // 4
-    {4, 256, bmx::ed_tile_kernel<4, 256, false>, nullptr}, // 5: the first version (ds_bpermute shuffle, predicated steps)
+    {4, 256, bmx::ed_tile_kernel<4, 256, false>, nullptr, nullptr}, // 5: the first version (ds_bpermute shuffle, predicated steps)
     BMX_ED(4, 512), // 6
     BMX_ED(3, 256), // 7
 };
 constexpr int N_ED_VARIANTS = sizeof(g_ed_variants) / sizeof(g_ed_variants[0]);
-constexpr int ED_ONE_DIRECTION = 16; // flag on the variant number: do not meet in the middle
+constexpr int ED_ONE_DIRECTION = 16; // flag on the variant number: tiles, from the top-left corner only
+constexpr int ED_TILES = 32;         // flag: tiles from both corners (one launch per pair of tile diagonals)
+constexpr int ED_FLAGS = ED_ONE_DIRECTION | ED_TILES;
+constexpr uint64_t ED_BAND_WS_LIMIT = 16ull << 30; // bytes of right-column storage the band pipeline may take
+
+// Band pipeline (bmx_ed_band_kernel.h).  Returns BMX_OK with *used = false if it does not apply
+// (workspace too large / allocation refused): the caller then takes the tile schedule.
+int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, const void *d_b, uint64_t lb,
+                hipStream_t stream, uint32_t *h_result, bool *used)
+{
+    *used = false;
+    const uint32_t W = 64u * v.c;
+    const uint32_t bands = (uint32_t)((la + W - 1) / W);
+    const uint64_t rc_words = 2ull * (bands + 1) * (lb + 1), stair_words = 2ull * bands * (W + 1);
+    const uint64_t words = rc_words + stair_words + 3ull * bands + 2;
+    if (words * sizeof(uint32_t) > ED_BAND_WS_LIMIT) return BMX_OK;
+    uint32_t *ws = nullptr;
+    if (hipMalloc(&ws, words * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        return BMX_OK;
+    }
+    // Cut rows: band J of the forward pipeline starts ~J*lag row-steps late, band J of the mirrored one
+    // (bands-1-J)*lag; both reach row cut[J] at the same time for cut[J] = (lb + (bands-1-2J)*lag) / 2.
+    int lag = 200;
+    if (const char *env = getenv("BMX_ED_LAG")) lag = atoi(env);
+    std::vector<uint32_t> cut(bands);
+    for (uint32_t J = 0; J < bands; ++J) {
+        const int64_t h = ((int64_t)lb + ((int64_t)bands - 1 - 2 * (int64_t)J) * lag) / 2;
+        cut[J] = (uint32_t)std::min<int64_t>(std::max<int64_t>(h, 0), (int64_t)lb);
+    }
+    bmx::EdBandArgs a = {};
+    a.a = (const uint8_t *)d_a;
+    a.b = (const uint8_t *)d_b;
+    a.la = (uint32_t)la;
+    a.lb = (uint32_t)lb;
+    a.bands = bands;
+    a.rc[0] = ws;
+    a.rc[1] = ws + rc_words / 2;
+    a.stair_row[0] = ws + rc_words;
+    a.stair_row[1] = ws + rc_words + stair_words / 2;
+    uint32_t *tail = ws + rc_words + stair_words; // [progress fwd | progress mirrored | cut | err | result]
+    a.progress[0] = tail;
+    a.progress[1] = tail + bands;
+    uint32_t *d_cut = tail + 2 * bands;
+    a.cut = d_cut;
+    a.err = d_cut + bands;
+    uint32_t *d_result = a.err + 1;
+    // generous: 10 s + 100x the time the tile schedule would need (100 MHz ticks)
+    a.timeout_ticks = 1000000000ull + (uint64_t)((double)la * (double)lb / 2.0e9 * 100.0);
+    const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
+    hipError_t e = hipMemcpyAsync(d_cut, cut.data(), bands * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream); // cut[] is a pageable host buffer
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev0[slot], stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bmx::ed_band_init_kernel, dim3(64), dim3(256), 0, stream, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(v.band, dim3(2 * bands), dim3(64), 0, stream, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bmx::ed_band_meet_kernel, dim3(1), dim3(1024), 0, stream, a, W, d_result);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1[slot], stream);
+    uint32_t h_tail[2] = {0, 0}; // err, result
+    if (e == hipSuccess) e = hipMemcpyAsync(h_tail, a.err, sizeof h_tail, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) (void)hipEventElapsedTime(&ctx->ed_last_ms, ctx->ev0[slot], ctx->ev1[slot]);
+    (void)hipFree(ws);
+    if (e != hipSuccess) {
+        set_err("bmx_edit_distance_device (band pipeline): %s", hipGetErrorString(e));
+        return BMX_ERR_HIP;
+    }
+    if (h_tail[0] != 0) {
+        set_err("bmx_edit_distance_device: a column band waited longer than the time limit for its neighbour");
+        return BMX_ERR_HIP;
+    }
+    *h_result = h_tail[1];
+    *used = true;
+    return BMX_OK;
+}
 } // namespace
 
 int bmx_set_ed_variant(bmx_ctx *ctx, int variant)
 {
-    if (!ctx || variant < 0 || (variant & ~ED_ONE_DIRECTION) >= N_ED_VARIANTS) return BMX_ERR_ARG;
+    if (!ctx || variant < 0 || (variant & ~ED_FLAGS) >= N_ED_VARIANTS) return BMX_ERR_ARG;
     ctx->ed_variant = variant;
     return BMX_OK;
 }
@@ -554,7 +639,17 @@ int bmx_edit_distance_device(bmx_ctx *ctx, const void *d_a, uint64_t la, const v
     }
     hipStream_t stream = (hipStream_t)stream_v;
     HIPCHK(hipSetDevice(ctx->device));
-    const EdVariant &v = g_ed_variants[ctx->ed_variant & ~ED_ONE_DIRECTION];
+    const EdVariant &v = g_ed_variants[ctx->ed_variant & ~ED_FLAGS];
+    if (v.band && !(ctx->ed_variant & ED_FLAGS)) {
+        uint32_t h = 0;
+        bool used = false;
+        const int rc = ed_band_run(ctx, v, d_a, la, d_b, lb, stream, &h, &used);
+        if (rc != BMX_OK) return rc;
+        if (used) {
+            *distance = h;
+            return BMX_OK;
+        }
+    }
     const uint32_t W = 64u * v.c, R = (uint32_t)v.r;
     bmx::EdArgs a = {};
     a.a = (const uint8_t *)d_a;

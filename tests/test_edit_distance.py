@@ -68,9 +68,9 @@ def test_gpu_vs_oracle_around_tile_edges_all_tile_shapes(ctx, port):
     rng = np.random.default_rng(7)
     lens = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 1025]
     try:
-        # 0..5: tile shapes, filled from both corners at once where there are three tile
-        # diagonals or more; +16: the same shapes filled from the top-left corner only
-        for v in [0, 1, 2, 3, 4, 5, 16, 17, 18, 20]:
+        # 0..7: columns per lane (band pipeline, one launch); +32: tiles filled from both corners at
+        # once where there are three tile diagonals or more; +16: tiles from the top-left corner only
+        for v in [0, 2, 4, 7, 5, 32, 33, 34, 35, 16, 17, 18, 20]:
             ctx.set_ed_variant(v)
             for _ in range(14):
                 la, lb = int(rng.choice(lens)), int(rng.choice(lens))
@@ -88,7 +88,7 @@ def test_gpu_two_ended_schedule_on_every_grid_shape(ctx, port):
     1..9 tiles (128 x 256 tiles, variant 1), full and ragged last tiles, strings that are
     related (long shared runs: the optimal path hugs the diagonal) and unrelated."""
     rng = np.random.default_rng(11)
-    ctx.set_ed_variant(1)
+    ctx.set_ed_variant(33)
     try:
         for tr in (1, 2, 3, 5, 9):
             for tc in (1, 2, 3, 4, 7):
@@ -109,6 +109,25 @@ def test_gpu_two_ended_schedule_on_every_grid_shape(ctx, port):
                     assert ctx.edit_distance(y, x) == want, (tc, tr, lb, la)
     finally:
         ctx.set_ed_variant(0)
+
+
+@pytest.mark.gpu
+def test_gpu_band_pipeline_cut_shapes(ctx, port, monkeypatch):
+    """The band pipeline's two directions meet on a staircase whose step is set by the assumed
+    lag between neighbouring bands: tiny lag = one flat cut row, huge lag = one direction does
+    whole bands alone (cut clipped to 0 / lb), in between = a real staircase."""
+    rng = np.random.default_rng(13)
+    shapes = [(1, 1), (70, 300), (300, 70), (257, 256), (256, 257), (1000, 1500), (1500, 1000), (3000, 513),
+              (513, 3000), (2048, 2048)]
+    for lag in ("0", "3", "64", "200", "700", "100000"):
+        monkeypatch.setenv("BMX_ED_LAG", lag)
+        for la, lb in shapes:
+            x = (rng.integers(0, 3, la) + 97).astype(np.uint8)
+            y = (rng.integers(0, 3, lb) + 97).astype(np.uint8)
+            if la == lb:
+                y = x.copy()
+                y[rng.integers(0, la, la // 7 + 1)] = ord("q")
+            assert ctx.edit_distance(x, y) == port.edit_distance(x, y), (lag, la, lb)
 
 
 @pytest.mark.gpu
@@ -154,9 +173,10 @@ def test_gpu_config5_64k_properties(ctx, port):
     dz = torch.from_numpy(z).cuda()
     d1 = ctx.edit_distance_device(dx, dz)
     assert d1 == ctx.edit_distance_device(dz, dx)
-    ctx.set_ed_variant(16)  # one direction only: the schedule of the first version
     try:
-        assert d1 == ctx.edit_distance_device(dx, dz)
+        for v in (16, 32):  # tiles from one corner (the first schedule) / from both corners
+            ctx.set_ed_variant(v)
+            assert d1 == ctx.edit_distance_device(dx, dz)
     finally:
         ctx.set_ed_variant(0)
     assert d1 == port.edit_distance(x, z)

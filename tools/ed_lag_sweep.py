@@ -1,0 +1,21 @@
+"""Band pipeline: time vs the lag assumed when placing the cut rows (BMX_ED_LAG) and columns per lane."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from parallel_implementation_of_string_matching_algorithms_opencl_amd import host
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+rng = np.random.default_rng(5)
+x = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
+z = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
+ctx = host.Context(0)
+for v in (0, 2, 4, 7):
+    ctx.set_ed_variant(v)
+    row = {}
+    for lag in (0, 100, 150, 200, 250, 300, 350, 400, 500, 700, 1000):
+        os.environ["BMX_ED_LAG"] = str(lag)
+        ms = []
+        for _ in range(4):
+            d = ctx.edit_distance_device(x, z)
+            ms.append(ctx.last_edit_distance_ms())
+        row[lag] = round(min(ms[1:]), 3)
+    print(json.dumps({"variant": v, "distance": d, "ms_by_lag": row}), flush=True)
