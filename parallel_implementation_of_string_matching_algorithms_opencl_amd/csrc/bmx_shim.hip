@@ -516,27 +516,33 @@ int bmx_scan_stamps(bmx_ctx *ctx, uint64_t *out, uint64_t max_words)
 // ---- edit distance ---------------------------------------------------
 namespace {
 struct EdVariant {
-    int c, r;
-    void (*kernel)(const bmx::EdArgs);   // one tile diagonal per launch, from the top-left corner
-    void (*dual)(const bmx::EdArgs);     // a forward and a mirrored tile diagonal per launch (nullptr: none)
-    void (*band)(const bmx::EdBandArgs); // the whole table in one launch: pipeline of column bands, both directions
+    int c, r;                              // tile schedules: 64*c columns x r rows per wave
+    void (*kernel)(const bmx::EdArgs);     // one tile diagonal per launch, from the top-left corner
+    void (*dual)(const bmx::EdArgs);       // a forward and a mirrored tile diagonal per launch (nullptr: none)
+    int band_c;                            // band pipeline: 64*band_c columns per wave
+    void (*band)(const bmx::EdBandArgs);   // the whole table in one launch: pipeline of column bands, both directions
+    void (*band16)(const bmx::EdBandArgs); // same with 16-row hand-over groups (experiments: BMX_ED_GROUP=16)
 };
-#define BMX_ED(C_, R_) {C_, R_, bmx::ed_tile_kernel<C_, R_, true>, bmx::ed_dual_kernel<C_, R_>, bmx::ed_band_kernel<C_>}
+#define BMX_ED(C_, R_, BC_)                                                                                     \
+    {C_, R_, bmx::ed_tile_kernel<C_, R_, true>, bmx::ed_dual_kernel<C_, R_>, BC_, bmx::ed_band_kernel<BC_, 32>, \
+     bmx::ed_band_kernel<BC_, 16>}
 const EdVariant g_ed_variants[] = {
-    BMX_ED(4, 256), // 0: default: tiles of 256 rows x 256 columns, lean step
-    BMX_ED(4, 128), // 1
-    BMX_ED(8, 256), // 2
-    BMX_ED(4, 384), // 3
-    BMX_ED(6, 256), // 4
-    {4, 256, bmx::ed_tile_kernel<4, 256, false>, nullptr, nullptr}, // 5: the first version (ds_bpermute shuffle, predicated steps)
-    BMX_ED(4, 512), // 6
-    BMX_ED(3, 256), // 7
+    BMX_ED(4, 256, 6), // 0: default: bands of 384 columns; tiles (fallback, +16, +32) of 256 rows x 256 columns
+    BMX_ED(4, 128, 4), // 1
+    BMX_ED(8, 256, 8), // 2
+    BMX_ED(4, 384, 5), // 3
+    BMX_ED(6, 256, 6), // 4
+    {4, 256, bmx::ed_tile_kernel<4, 256, false>, nullptr, 0, nullptr, nullptr}, // 5: the first version (ds_bpermute
+                                                                                // shuffle, predicated steps)
+    BMX_ED(4, 512, 7), // 6
+    BMX_ED(3, 256, 3), // 7
 };
 constexpr int N_ED_VARIANTS = sizeof(g_ed_variants) / sizeof(g_ed_variants[0]);
 constexpr int ED_ONE_DIRECTION = 16; // flag on the variant number: tiles, from the top-left corner only
 constexpr int ED_TILES = 32;         // flag: tiles from both corners (one launch per pair of tile diagonals)
 constexpr int ED_FLAGS = ED_ONE_DIRECTION | ED_TILES;
 constexpr uint64_t ED_BAND_WS_LIMIT = 16ull << 30; // bytes of right-column storage the band pipeline may take
+constexpr int ED_BAND_LAG = 160;                   // rows a band trails its predecessor by (measured; sets the cut rows)
 
 // Band pipeline (bmx_ed_band_kernel.h).  Returns BMX_OK with *used = false if it does not apply
 // (workspace too large / allocation refused): the caller then takes the tile schedule.
@@ -544,19 +550,20 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
                 hipStream_t stream, uint32_t *h_result, bool *used)
 {
     *used = false;
-    const uint32_t W = 64u * v.c;
+    const uint32_t W = 64u * v.band_c;
     const uint32_t bands = (uint32_t)((la + W - 1) / W);
-    const uint64_t rc_words = 2ull * (bands + 1) * (lb + 1), stair_words = 2ull * bands * (W + 1);
-    const uint64_t words = rc_words + stair_words + 3ull * bands + 2;
-    if (words * sizeof(uint32_t) > ED_BAND_WS_LIMIT) return BMX_OK;
-    uint32_t *ws = nullptr;
-    if (hipMalloc(&ws, words * sizeof(uint32_t)) != hipSuccess) {
+    // [right columns: 2 x (bands + 1) x (lb + 1) entries of 8 B | cut rows: 2 x bands x (W + 1) | cut | err | result]
+    const uint64_t rc_entries = 2ull * (bands + 1) * (lb + 1), stair_words = 2ull * bands * (W + 1);
+    const uint64_t bytes = rc_entries * sizeof(uint64_t) + (stair_words + bands + 2) * sizeof(uint32_t);
+    if (bytes > ED_BAND_WS_LIMIT) return BMX_OK;
+    uint64_t *ws = nullptr;
+    if (hipMalloc(&ws, bytes) != hipSuccess) {
         (void)hipGetLastError();
         return BMX_OK;
     }
     // Cut rows: band J of the forward pipeline starts ~J*lag row-steps late, band J of the mirrored one
     // (bands-1-J)*lag; both reach row cut[J] at the same time for cut[J] = (lb + (bands-1-2J)*lag) / 2.
-    int lag = 200;
+    int lag = ED_BAND_LAG;
     if (const char *env = getenv("BMX_ED_LAG")) lag = atoi(env);
     std::vector<uint32_t> cut(bands);
     for (uint32_t J = 0; J < bands; ++J) {
@@ -570,28 +577,29 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     a.lb = (uint32_t)lb;
     a.bands = bands;
     a.rc[0] = ws;
-    a.rc[1] = ws + rc_words / 2;
-    a.stair_row[0] = ws + rc_words;
-    a.stair_row[1] = ws + rc_words + stair_words / 2;
-    uint32_t *tail = ws + rc_words + stair_words; // [progress fwd | progress mirrored | cut | err | result]
-    a.progress[0] = tail;
-    a.progress[1] = tail + bands;
-    uint32_t *d_cut = tail + 2 * bands;
+    a.rc[1] = ws + rc_entries / 2;
+    uint32_t *tail = (uint32_t *)(ws + rc_entries);
+    a.stair_row[0] = tail;
+    a.stair_row[1] = tail + stair_words / 2;
+    uint32_t *d_cut = tail + stair_words;
     a.cut = d_cut;
     a.err = d_cut + bands;
     uint32_t *d_result = a.err + 1;
+    a.tag = 1; // the right-column storage is zeroed below: tag 0 = "not produced yet"
     // generous: 10 s + 100x the time the tile schedule would need (100 MHz ticks)
     a.timeout_ticks = 1000000000ull + (uint64_t)((double)la * (double)lb / 2.0e9 * 100.0);
     const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
     hipError_t e = hipMemcpyAsync(d_cut, cut.data(), bands * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream); // cut[] is a pageable host buffer
     if (e == hipSuccess) e = hipEventRecord(ctx->ev0[slot], stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ws, 0, rc_entries * sizeof(uint64_t), stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(bmx::ed_band_init_kernel, dim3(64), dim3(256), 0, stream, a);
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(v.band, dim3(2 * bands), dim3(64), 0, stream, a);
+        const char *grp = getenv("BMX_ED_GROUP");
+        hipLaunchKernelGGL(grp && atoi(grp) == 16 ? v.band16 : v.band, dim3(2 * bands), dim3(64), 0, stream, a);
         e = hipGetLastError();
     }
     if (e == hipSuccess) {

@@ -8,14 +8,15 @@ rng = np.random.default_rng(5)
 x = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 z = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 ctx = host.Context(0)
-for v in (0, 2, 4, 7):
+for v, grp in ((0, 32), (0, 16), (4, 32), (4, 16), (2, 32), (2, 16)):
     ctx.set_ed_variant(v)
+    os.environ["BMX_ED_GROUP"] = str(grp)
     row = {}
-    for lag in (0, 100, 150, 200, 250, 300, 350, 400, 500, 700, 1000):
+    for lag in (60, 100, 120, 140, 160, 180, 200, 220, 250, 300):
         os.environ["BMX_ED_LAG"] = str(lag)
         ms = []
         for _ in range(4):
             d = ctx.edit_distance_device(x, z)
             ms.append(ctx.last_edit_distance_ms())
         row[lag] = round(min(ms[1:]), 3)
-    print(json.dumps({"variant": v, "distance": d, "ms_by_lag": row}), flush=True)
+    print(json.dumps({"variant": v, "group": grp, "distance": d, "ms_by_lag": row}), flush=True)
