@@ -194,10 +194,10 @@ int bmx_edit_distance(bmx_ctx *ctx, const char *a, uint64_t la, const char *b, u
                       uint64_t *distance);
 int bmx_edit_distance_device(bmx_ctx *ctx, const void *d_a, uint64_t la, const void *d_b, uint64_t lb,
                              uint64_t *distance, void *stream);
-/* Device time (ms, HIP events around all tile-diagonal launches) of the last call. */
+/* Device time (ms, HIP events around the kernels) of the last call. */
 float bmx_last_edit_distance_ms(bmx_ctx *ctx);
-/* Kernel shape for experiments: 0 = default (4 columns per lane = 256 per wave; one launch, a
- * pipeline of column bands from both corners); +32 = one launch per pair of tile diagonals from
+/* Kernel shape for experiments: 0 = default (one launch, a pipeline of column bands of 384
+ * columns from both corners of the table); +32 = one launch per pair of tile diagonals from
  * both corners; +16 = one launch per tile diagonal from the top-left corner only. */
 int bmx_set_ed_variant(bmx_ctx *ctx, int variant);
 

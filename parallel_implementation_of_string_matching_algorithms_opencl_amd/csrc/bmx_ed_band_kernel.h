@@ -276,31 +276,34 @@ __global__ void ed_band_init_kernel(const EdBandArgs a)
         f_edge[r] = ed_entry(0u, a.tag); // D[r][0] = r        -> F = 0
         g_edge[r] = ed_entry(0u, a.tag); // mirrored: lb - r   -> F = 0
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *a.err = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.err[0] = 0;
+        a.err[1] = 0x7FFFFFFFu; // the meet kernel's running minimum lives next to the flag
+    }
 }
 
-// distance = min of F + G over the staircase between the two directions:
-//   cut rows:   vertex (cut[J], c), c in band J            -> the two bands' stair_row
-//   band edges: vertex (r, right edge of band J), cut[J+1] <= r <= cut[J] -> forward rc of J, mirrored rc of J+1
-__global__ __launch_bounds__(1024) void ed_band_meet_kernel(const EdBandArgs a, uint32_t W, uint32_t *result)
+// min of F_fwd + F_mir (both <= 0; the distance is that + la + lb) over the staircase between the
+// two directions, one workgroup per band J, atomicMin into *best (preset to INT_MAX by the init kernel):
+//   cut row:   vertex (cut[J], c), c in band J                              -> the two bands' stair_row
+//   band edge: vertex (r, right edge of band J), cut[J+1] <= r <= cut[J]    -> forward rc of J, mirrored rc of J+1
+__global__ __launch_bounds__(256) void ed_band_meet_kernel(const EdBandArgs a, uint32_t W, int32_t *best_out)
 {
-    __shared__ int32_t s_min[16];
-    int32_t best = 0x7FFFFFFF; // over F_fwd + F_mir (both <= 0); the distance is that + la + lb
-    for (uint32_t J = 0; J < a.bands; ++J) {
-        const uint32_t col0 = J * W;
-        const uint32_t ncols = a.la - col0 < W ? a.la - col0 : W;
-        const uint32_t *f = a.stair_row[0] + (uint64_t)J * (W + 1), *g = a.stair_row[1] + (uint64_t)J * (W + 1);
-        for (uint32_t i = threadIdx.x; i <= ncols; i += 1024) {
-            const int32_t v = (int32_t)f[i] + (int32_t)g[i];
+    __shared__ int32_t s_min[4];
+    const uint32_t J = blockIdx.x;
+    int32_t best = 0x7FFFFFFF;
+    const uint32_t col0 = J * W;
+    const uint32_t ncols = a.la - col0 < W ? a.la - col0 : W;
+    const uint32_t *f = a.stair_row[0] + (uint64_t)J * (W + 1), *g = a.stair_row[1] + (uint64_t)J * (W + 1);
+    for (uint32_t i = threadIdx.x; i <= ncols; i += 256) {
+        const int32_t v = (int32_t)f[i] + (int32_t)g[i];
+        best = v < best ? v : best;
+    }
+    if (J + 1 < a.bands) {
+        const uint32_t lo = a.cut[J + 1], hi = a.cut[J];
+        const uint64_t *fc = a.rc[0] + (uint64_t)(J + 1) * (a.lb + 1), *gc = a.rc[1] + (uint64_t)(J + 1) * (a.lb + 1);
+        for (uint32_t r = lo + threadIdx.x; r <= hi; r += 256) {
+            const int32_t v = (int32_t)(uint32_t)fc[r] + (int32_t)(uint32_t)gc[r];
             best = v < best ? v : best;
-        }
-        if (J + 1 < a.bands) {
-            const uint32_t lo = a.cut[J + 1], hi = a.cut[J];
-            const uint64_t *fc = a.rc[0] + (uint64_t)(J + 1) * (a.lb + 1), *gc = a.rc[1] + (uint64_t)(J + 1) * (a.lb + 1);
-            for (uint32_t r = lo + threadIdx.x; r <= hi; r += 1024) {
-                const int32_t v = (int32_t)(uint32_t)fc[r] + (int32_t)(uint32_t)gc[r];
-                best = v < best ? v : best;
-            }
         }
     }
     for (int off = 32; off; off >>= 1) {
@@ -310,8 +313,8 @@ __global__ __launch_bounds__(1024) void ed_band_meet_kernel(const EdBandArgs a, 
     if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) best = s_min[w] < best ? s_min[w] : best;
-        *result = (uint32_t)(best + (int32_t)a.la + (int32_t)a.lb);
+        for (int w = 1; w < 4; ++w) best = s_min[w] < best ? s_min[w] : best;
+        atomicMin(best_out, best);
     }
 }
 

@@ -555,7 +555,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     // [right columns: 2 x (bands + 1) x (lb + 1) entries of 8 B | cut rows: 2 x bands x (W + 1) | cut | err | result]
     const uint64_t rc_entries = 2ull * (bands + 1) * (lb + 1), stair_words = 2ull * bands * (W + 1);
     const uint64_t bytes = rc_entries * sizeof(uint64_t) + (stair_words + bands + 2) * sizeof(uint32_t);
-    if (bytes > ED_BAND_WS_LIMIT) return BMX_OK;
+    if (bytes > ED_BAND_WS_LIMIT || la + lb >= (1ull << 31)) return BMX_OK; // (the kernel's F = D - r - c is an int32)
     uint64_t *ws = nullptr;
     if (hipMalloc(&ws, bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -603,7 +603,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(bmx::ed_band_meet_kernel, dim3(1), dim3(1024), 0, stream, a, W, d_result);
+        hipLaunchKernelGGL(bmx::ed_band_meet_kernel, dim3(bands), dim3(256), 0, stream, a, W, (int32_t *)d_result);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(ctx->ev1[slot], stream);
@@ -620,7 +620,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
         set_err("bmx_edit_distance_device: a column band waited longer than the time limit for its neighbour");
         return BMX_ERR_HIP;
     }
-    *h_result = h_tail[1];
+    *h_result = (uint32_t)((int64_t)(int32_t)h_tail[1] + (int64_t)la + (int64_t)lb); // min(F_fwd + F_mir) + la + lb
     *used = true;
     return BMX_OK;
 }
