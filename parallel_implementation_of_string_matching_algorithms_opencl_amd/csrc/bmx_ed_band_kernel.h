@@ -58,7 +58,8 @@ struct EdBandArgs {
     const uint8_t *b; // rows, lb characters
     uint32_t la, lb;
     uint32_t bands;         // ceil(la / W)
-    const uint32_t *cut;    // [bands], non-increasing, 0 <= cut[J] <= lb
+    uint32_t *cut;          // [bands], non-increasing, 0 <= cut[J] <= lb (filled by ed_band_init_kernel)
+    int32_t lag;            // rows a band is expected to trail its predecessor by: places the cut rows
     uint64_t *rc[2];        // per direction: (bands + 1) x (lb + 1) entries {value, tag << 32} at vertex (row, a band's
                             // far edge); one slot per band plus the table's own edge column as the first band's
                             // "previous band": forward band J -> slot J + 1 (slot 0: F[r][0] = r), mirrored band J ->
@@ -267,10 +268,17 @@ __global__ __launch_bounds__(64) void ed_band_kernel(const EdBandArgs a)
     }
 }
 
-// the table's edge columns as "band -1" of either direction (valid entries), error flag cleared;
-// the rest of the right-column storage has been zeroed (tag 0 = not produced yet)
+// The table's edge columns as "band -1" of either direction (valid entries), error flag cleared, and
+// the cut rows: band J of the forward pipeline starts ~J*lag row steps late, band J of the mirrored
+// one (bands-1-J)*lag, so both reach row cut[J] = (lb + (bands-1-2J)*lag) / 2 at the same time.
+// No other entry of the right-column storage carries this call's tag (zeroed when newly allocated,
+// older tags of this process otherwise).
 __global__ void ed_band_init_kernel(const EdBandArgs a)
 {
+    for (uint32_t J = blockIdx.x * blockDim.x + threadIdx.x; J < a.bands; J += gridDim.x * blockDim.x) {
+        const long long h = ((long long)a.lb + ((long long)a.bands - 1 - 2 * (long long)J) * a.lag) / 2;
+        a.cut[J] = (uint32_t)(h < 0 ? 0 : (h > (long long)a.lb ? (long long)a.lb : h));
+    }
     uint64_t *f_edge = a.rc[0], *g_edge = a.rc[1] + (uint64_t)a.bands * (a.lb + 1);
     for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r <= a.lb; r += gridDim.x * blockDim.x) {
         f_edge[r] = ed_entry(0u, a.tag); // D[r][0] = r        -> F = 0

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -118,6 +119,9 @@ struct bmx_ctx {
     int last_variant = 0;    // what the most recent search ran (bmx_scan_geometry reports it)
     int ed_variant = 0;      // edit-distance tile shape (bmx_set_ed_variant)
     float ed_last_ms = -1.0f;
+    void *ed_ws = nullptr;   // band pipeline workspace, kept between calls while it is small
+    uint64_t ed_ws_bytes = 0;
+    uint64_t ed_ws_shape[3] = {0, 0, 0}; // (la, lb, W) of the call that last used it: same layout, stale tags only
     float sa_last_ms = -1.0f;
     int sa_last_rounds = 0;
     int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
@@ -274,6 +278,7 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
+    if (ctx->ed_ws) (void)hipFree(ctx->ed_ws);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (int i = 0; i < bmx_ctx::EV_RING; ++i) {
         if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
@@ -542,6 +547,7 @@ constexpr int ED_ONE_DIRECTION = 16; // flag on the variant number: tiles, from 
 constexpr int ED_TILES = 32;         // flag: tiles from both corners (one launch per pair of tile diagonals)
 constexpr int ED_FLAGS = ED_ONE_DIRECTION | ED_TILES;
 constexpr uint64_t ED_BAND_WS_LIMIT = 16ull << 30; // bytes of right-column storage the band pipeline may take
+constexpr uint64_t ED_BAND_WS_KEEP = 1ull << 30;   // workspaces up to this size stay in the context between calls
 constexpr int ED_BAND_LAG = 160;                   // rows a band trails its predecessor by (measured; sets the cut rows)
 
 // Band pipeline (bmx_ed_band_kernel.h).  Returns BMX_OK with *used = false if it does not apply
@@ -556,20 +562,42 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     const uint64_t rc_entries = 2ull * (bands + 1) * (lb + 1), stair_words = 2ull * bands * (W + 1);
     const uint64_t bytes = rc_entries * sizeof(uint64_t) + (stair_words + bands + 2) * sizeof(uint32_t);
     if (bytes > ED_BAND_WS_LIMIT || la + lb >= (1ull << 31)) return BMX_OK; // (the kernel's F = D - r - c is an int32)
+    // Workspace: kept in the context between calls while it is small (a fresh hipMalloc + hipFree per
+    // call costs 0.3 ms next to a 4 ms kernel).  Entries are valid only with this call's tag; tags are
+    // unique per process, so a workspace reused for the same shape needs no clearing -- a new allocation
+    // (or another shape) is zeroed first.
+    static std::atomic<uint32_t> g_tag{0};
+    uint32_t tag = ++g_tag;
+    bool fresh = false;
     uint64_t *ws = nullptr;
-    if (hipMalloc(&ws, bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        return BMX_OK;
+    if (ctx->ed_ws && ctx->ed_ws_bytes >= bytes && tag != 0) {
+        ws = (uint64_t *)ctx->ed_ws;
+        // another shape lays the regions out differently: what was a cut row or a result word may now
+        // be read as an entry, so the storage is cleared like a new one
+        fresh = ctx->ed_ws_shape[0] != la || ctx->ed_ws_shape[1] != lb || ctx->ed_ws_shape[2] != W;
+    } else {
+        if (ctx->ed_ws) (void)hipFree(ctx->ed_ws);
+        ctx->ed_ws = nullptr;
+        ctx->ed_ws_bytes = 0;
+        if (hipMalloc(&ws, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return BMX_OK;
+        }
+        fresh = true;
+        if (tag == 0) tag = ++g_tag; // 2^32 calls later: start over on zeroed storage
+        if (bytes <= ED_BAND_WS_KEEP) {
+            ctx->ed_ws = ws;
+            ctx->ed_ws_bytes = bytes;
+        }
     }
-    // Cut rows: band J of the forward pipeline starts ~J*lag row-steps late, band J of the mirrored one
-    // (bands-1-J)*lag; both reach row cut[J] at the same time for cut[J] = (lb + (bands-1-2J)*lag) / 2.
+    const bool keep = ctx->ed_ws == (void *)ws;
+    if (keep) {
+        ctx->ed_ws_shape[0] = la;
+        ctx->ed_ws_shape[1] = lb;
+        ctx->ed_ws_shape[2] = W;
+    }
     int lag = ED_BAND_LAG;
     if (const char *env = getenv("BMX_ED_LAG")) lag = atoi(env);
-    std::vector<uint32_t> cut(bands);
-    for (uint32_t J = 0; J < bands; ++J) {
-        const int64_t h = ((int64_t)lb + ((int64_t)bands - 1 - 2 * (int64_t)J) * lag) / 2;
-        cut[J] = (uint32_t)std::min<int64_t>(std::max<int64_t>(h, 0), (int64_t)lb);
-    }
     bmx::EdBandArgs a = {};
     a.a = (const uint8_t *)d_a;
     a.b = (const uint8_t *)d_b;
@@ -585,14 +613,13 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     a.cut = d_cut;
     a.err = d_cut + bands;
     uint32_t *d_result = a.err + 1;
-    a.tag = 1; // the right-column storage is zeroed below: tag 0 = "not produced yet"
+    a.tag = tag;
+    a.lag = lag;
     // generous: 10 s + 100x the time the tile schedule would need (100 MHz ticks)
     a.timeout_ticks = 1000000000ull + (uint64_t)((double)la * (double)lb / 2.0e9 * 100.0);
     const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
-    hipError_t e = hipMemcpyAsync(d_cut, cut.data(), bands * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream); // cut[] is a pageable host buffer
-    if (e == hipSuccess) e = hipEventRecord(ctx->ev0[slot], stream);
-    if (e == hipSuccess) e = hipMemsetAsync(ws, 0, rc_entries * sizeof(uint64_t), stream);
+    hipError_t e = hipEventRecord(ctx->ev0[slot], stream);
+    if (e == hipSuccess && fresh) e = hipMemsetAsync(ws, 0, rc_entries * sizeof(uint64_t), stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(bmx::ed_band_init_kernel, dim3(64), dim3(256), 0, stream, a);
         e = hipGetLastError();
@@ -611,7 +638,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     if (e == hipSuccess) e = hipMemcpyAsync(h_tail, a.err, sizeof h_tail, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e == hipSuccess) (void)hipEventElapsedTime(&ctx->ed_last_ms, ctx->ev0[slot], ctx->ev1[slot]);
-    (void)hipFree(ws);
+    if (!keep) (void)hipFree(ws);
     if (e != hipSuccess) {
         set_err("bmx_edit_distance_device (band pipeline): %s", hipGetErrorString(e));
         return BMX_ERR_HIP;
