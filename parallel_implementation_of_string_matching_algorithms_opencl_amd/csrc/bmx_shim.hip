@@ -104,6 +104,11 @@ const Variant g_variants[] = {
     BMX_WAVE(8, 100, 2, 2, 2, 3),       // 17: walkers only, wave streams
     BMX_TILE(1024, 68, 2, 3, 0),        // 18: only wave 0 of each workgroup walks
     BMX_TILE_L(1024, 68, 2, 1, 0, 1),   // 19: DMA only through ONE loader wave
+    // ---- more products under test (valid match lists) ----
+    BMX_TILE(512, 68, 2, 0, 0),         // 20: two workgroups of 8 waves per CU, 34 KiB tiles
+    BMX_TILE(512, 76, 2, 0, 0),         // 21: same, 38 KiB tiles
+    BMX_TILE(512, 132, 2, 0, 0),        // 22: one workgroup of 8 waves, 66 KiB tiles
+    BMX_TILE(1024, 36, 2, 0, 0),        // 23: variant 2's geometry with the byte-wise walker
 };
 constexpr int N_PRODUCT_VARIANTS = 12;
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
