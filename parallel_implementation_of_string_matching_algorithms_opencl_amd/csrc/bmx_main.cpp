@@ -14,6 +14,11 @@
 //                             inclusive ranges like BoyreMoore.cpp:94-141 and
 //                             print the per-range counts of bmx_search_ranges
 //           [--device D]
+//   bmx_cli --edit-distance A B [--iters N]   the reference's second program (EditDistance-1.cpp:
+//                             two strings from files -- it opens str1.txt twice, :94-95 -- the mean time
+//                             of the runs and the distance, :358-383)
+//   bmx_cli --suffix-array F [--iters N] [--max-print K]   its third (SuffixArrays.cpp: text from
+//                             input.txt, :181; array printed, :155-161; mean time, :514)
 //           [--gpus G]        also run the search over G GPUs from this one process
 //                             (bmx_search_multi: G shards, one host thread each) and
 //                             check its list against the one-GPU list
@@ -73,7 +78,7 @@ std::vector<int32_t> split_like_reference(const std::string &text, int P)
 
 int main(int argc, char **argv)
 {
-    std::string text_path = "inputEd.txt", pat_path = "input1Search.txt";
+    std::string text_path = "inputEd.txt", pat_path = "input1Search.txt", ed_a, ed_b, sa_path;
     int iters = 10, device = 0, ranges = 0, gpus = 0;
     bool positions = false;
     uint64_t max_print = 32;
@@ -94,10 +99,68 @@ int main(int argc, char **argv)
         else if (a == "--ranges") ranges = atoi(need("--ranges"));
         else if (a == "--max-print") max_print = strtoull(need("--max-print"), nullptr, 10);
         else if (a == "--positions") positions = true;
+        else if (a == "--edit-distance") {
+            ed_a = need("--edit-distance");
+            ed_b = need("--edit-distance");
+        } else if (a == "--suffix-array") sa_path = need("--suffix-array");
         else {
             fprintf(stderr, "unknown option %s\n", a.c_str());
             return 2;
         }
+    }
+
+    if (!ed_a.empty() || !sa_path.empty()) {
+        bmx_ctx *ctx = nullptr;
+        int rc = bmx_ctx_create(device, &ctx);
+        if (rc != BMX_OK) {
+            fprintf(stderr, "bmx_ctx_create failed: %d (%s)\n", rc, bmx_last_error());
+            return 1;
+        }
+        double total = 0.0;
+        if (!ed_a.empty()) {
+            std::string x, y;
+            if (!read_file(ed_a, x) || !read_file(ed_b, y)) {
+                fprintf(stderr, "File Not Found!\n"); // EditDistance-1.cpp:99
+                return 1;
+            }
+            uint64_t d = 0;
+            for (int it = 0; it < iters; ++it) {
+                auto t0 = std::chrono::steady_clock::now();
+                rc = bmx_edit_distance(ctx, x.data(), x.size(), y.data(), y.size(), &d);
+                auto t1 = std::chrono::steady_clock::now();
+                if (rc != BMX_OK) {
+                    fprintf(stderr, "bmx_edit_distance failed: %d (%s)\n", rc, bmx_last_error());
+                    return 1;
+                }
+                total += std::chrono::duration<double>(t1 - t0).count();
+            }
+            printf("%llu %llu\n", (unsigned long long)x.size(), (unsigned long long)y.size());
+            printf("%llu\n", (unsigned long long)d);                                  // :369
+            if (iters > 0) printf("\n\nAverage time :%f \n", total / iters);          // :383
+        } else {
+            std::string t;
+            if (!read_file(sa_path, t)) {
+                fprintf(stderr, "File Not Found!\n"); // SuffixArrays.cpp:185
+                return 1;
+            }
+            std::vector<int32_t> sa(t.size() ? t.size() : 1);
+            for (int it = 0; it < iters; ++it) {
+                auto t0 = std::chrono::steady_clock::now();
+                rc = bmx_suffix_array(ctx, t.data(), t.size(), sa.data());
+                auto t1 = std::chrono::steady_clock::now();
+                if (rc != BMX_OK) {
+                    fprintf(stderr, "bmx_suffix_array failed: %d (%s)\n", rc, bmx_last_error());
+                    return 1;
+                }
+                total += std::chrono::duration<double>(t1 - t0).count();
+            }
+            printf("%llu\n", (unsigned long long)t.size()); // :198
+            for (uint64_t i = 0; i < t.size() && i < max_print; ++i) printf("%d ", sa[i]); // :158-160
+            printf("\n");
+            if (iters > 0) printf("Average Time  = %f\n", total / iters); // :514
+        }
+        bmx_ctx_destroy(ctx);
+        return 0;
     }
 
     std::string text, pat;

@@ -412,3 +412,28 @@ def test_cpp_driver_on_a_reference_corpus_file(ctx, tmp_path):
     assert "Found at : 37" in r.stdout
     assert "Average time" in r.stdout and "process 1 is" in r.stdout
     assert "1 GPUs, host buffers in and out: 1098 occurrences" in r.stdout and "identical to" in r.stdout
+
+
+def test_cpp_driver_second_and_third_program(ctx, port, tmp_path):
+    """bmx_cli --edit-distance / --suffix-array: the I/O contracts of EditDistance-1.cpp and SuffixArrays.cpp."""
+    exe = os.path.join(ROOT, "parallel_implementation_of_string_matching_algorithms_opencl_amd", "bin", "bmx_cli")
+    raw = golden_file_bytes("input5L.txt.gz")
+    a, b = raw[:3000], raw[1500:4000]
+    (tmp_path / "str1.txt").write_bytes(a)
+    (tmp_path / "str2.txt").write_bytes(b)
+    r = subprocess.run([exe, "--edit-distance", "str1.txt", "str2.txt", "--iters", "2"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    assert lines[0] == "3000 2500" and int(lines[1]) == port.edit_distance(a, b) and "Average time" in r.stdout
+    txt = raw[:5000].lower().replace(b" ", b"a")
+    txt = bytes(c for c in txt if 97 <= c <= 122) + b"z"  # the reference ranks signed char - 'a': lower case
+    (tmp_path / "input.txt").write_bytes(txt)
+    r = subprocess.run([exe, "--suffix-array", "input.txt", "--iters", "1", "--max-print", str(len(txt))], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.split("\n")
+    assert int(lines[0]) == len(txt)
+    assert [int(x) for x in lines[1].split()] == port.suffix_array(np.frombuffer(txt, dtype=np.uint8)).tolist()
+    r = subprocess.run([exe, "--edit-distance", "nope.txt", "str2.txt"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "File Not Found" in r.stderr
