@@ -26,8 +26,8 @@
 // edges the direction starts at).  Then F[r][c] = min3(F[r][c-1], F[r-1][c], F[r-1][c-1] + ne - 2):
 // three instructions per cell (compare, add-with-carry, min3) instead of four, and every table
 // edge is simply 0.  For the meet, (F_fwd + r + c) + (F_mir + (lb - r) + (la - c)) = F_fwd + F_mir +
-// la + lb.  The value the band's last column produces is collected with v_readlane/v_writelane
-// into a register (row r in lane r & (G - 1)) instead of going through LDS.
+// la + lb.  The values the band's last column produces are collected in a register that
+// rotates by one lane per step (DPP wave_rol:1) instead of going through LDS.
 //
 // Both directions run in the same launch (meet in the middle, as ed_dual_kernel): forward band J
 // fills rows 0..cut[J] from the top, the mirrored band fills rows lb..cut[J] from the bottom with
@@ -71,13 +71,6 @@ struct EdBandArgs {
 };
 
 __device__ __forceinline__ uint64_t ed_entry(uint32_t value, uint32_t tag) { return ((uint64_t)tag << 32) | value; }
-
-// acc[lane `slot`] = value; both wave-uniform.  hipcc 7.2 has no __builtin_amdgcn_writelane, and
-// the instruction may name only one SGPR: the lane select goes through M0.
-__device__ __forceinline__ void ed_writelane(uint32_t &acc, uint32_t value, uint32_t slot)
-{
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(acc) : "s"(value), "s"(slot) : "m0");
-}
 
 template <int C, int GROUP>
 __global__ __launch_bounds__(64) void ed_band_kernel(const EdBandArgs a)
@@ -147,7 +140,8 @@ __global__ __launch_bounds__(64) void ed_band_kernel(const EdBandArgs a)
 
     uint32_t last = 0, bc = 0;
     const uint32_t out_lane = (ncols - 1) / C, out_k = (ncols - 1) % C;
-    uint32_t acc = 0; // what my last column produced: row r in lane r & (G - 1)
+    uint32_t acc = 0; // what my last column produced: the row finished t steps ago in lane out_lane - t (mod 64)
+    const bool is_out = lane == out_lane;
     uint32_t win_left = 0, win_b = 0; // the 64-row windows: row r in lane r & 63
     auto step = [&](uint32_t s, auto check_tag, auto narrow_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
@@ -178,11 +172,11 @@ __global__ __launch_bounds__(64) void ed_band_kernel(const EdBandArgs a)
 #pragma unroll
             for (int k = 0; k < C - 1; ++k) outv = out_k == (uint32_t)k ? H[k] : outv;
         }
-        // out_lane has just finished row s - out_lane (v_writelane ignores EXEC; a step in which out_lane
-        // has no row writes a slot that is not handed over, or one that already has been)
-        const uint32_t sv = __builtin_amdgcn_readlane(outv, out_lane);
-        const uint32_t slot = (s - out_lane) & (G - 1);
-        ed_writelane(acc, sv, slot);
+        // out_lane has just finished row s - out_lane: rotate the collector by one lane and drop the new
+        // value in at out_lane, so the row finished t steps ago sits t lanes below it (all lanes enabled;
+        // a step in which out_lane has no row collects a value that is never handed over)
+        const uint32_t rot = __builtin_amdgcn_update_dpp(acc, acc, 0x134 /* wave_rol:1 */, 0xF, 0xF, false);
+        acc = is_out ? outv : rot;
     };
     // keep the part of the window that rows [first, first + G) live in
     auto merge = [&](uint32_t &win, uint32_t fresh, uint32_t first) {
@@ -213,8 +207,10 @@ __global__ __launch_bounds__(64) void ed_band_kernel(const EdBandArgs a)
     auto publish = [&](uint32_t done_steps) {
         uint32_t done = done_steps > out_lane ? done_steps - out_lane : 0; // rows 0 .. done-1 are final
         done = done < nrows ? done : nrows;
-        const uint32_t rr = published + ((lane - published) & (G - 1)); // the new row that lives in my lane
-        if (lane < G && rr < done)
+        // after step done_steps - 1, row rr (finished in step rr + out_lane) lives in lane
+        // out_lane - (done_steps - 1 - rr - out_lane) mod 64: the not yet handed over row that lives in MY lane
+        const uint32_t rr = published + ((lane - 2u * out_lane + done_steps - 1u - published) & 63u);
+        if (done_steps > 0 && rr < done)
             __hip_atomic_store(my_rc + phys_r(rr + 1), ed_entry(acc, a.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         published = done;
     };
