@@ -13,8 +13,9 @@
 //     and read with one 64-bit agent-scope load; an entry is valid when its tag is this call's tag
 //     (the workspace is zeroed before the launch, the tag is never 0).  No counters, no fences, no
 //     store-acknowledge wait: a row is usable the moment its own store is visible.
-//   * the consumer keeps a 64-row window of entry values in one register (row r in lane r & 63, read
-//     by v_readlane as the rows enter lane 0) and refills it G = 32 rows at a time: at every G-step
+//   * the consumer keeps a 64-row window of entry values in one register (before step s: row s + l in
+//     lane l; lane 0 feeds the systolic array, then the window moves up one lane by DPP wave_rol:1)
+//     and refills it G = 32 rows at a time: at every G-step
 //     boundary it merges the group it requested one boundary earlier (validating the tags; only then
 //     it may have to wait) and requests the next one, 2G..3G-1 rows ahead of the row entering lane 0.
 //     So a band trails its predecessor by 63 (systolic ramp) + 2G rows + the store-to-load latency:
@@ -142,16 +143,22 @@ __global__ __launch_bounds__(64) void ed_band_kernel(const EdBandArgs a)
     const uint32_t out_lane = (ncols - 1) / C, out_k = (ncols - 1) % C;
     uint32_t acc = 0; // what my last column produced: the row finished t steps ago in lane out_lane - t (mod 64)
     const bool is_out = lane == out_lane;
-    uint32_t win_left = 0, win_b = 0; // the 64-row windows: row r in lane r & 63
+    uint32_t win_left = 0, win_b = 0; // the row windows: before step s, row s + l in lane l (l < 2G)
     auto step = [&](uint32_t s, auto check_tag, auto narrow_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
         constexpr bool NARROW = decltype(narrow_tag)::value; // band narrower than W: last column is not lane 63's
         const bool active = !CHECK || (lane <= s && lane + nrows > s);
-        const uint32_t j = s & 63u;
-        const uint32_t left0 = __builtin_amdgcn_readlane(win_left, j);
-        const uint32_t bc0 = __builtin_amdgcn_readlane(win_b, j);
-        uint32_t left = __builtin_amdgcn_update_dpp(left0, last, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-        bc = __builtin_amdgcn_update_dpp(bc0, bc, 0x138, 0xF, 0xF, false);
+        // lane 0 takes this row's entry value and character out of lane 0 of the windows, every other
+        // lane takes them from its left neighbour (wave_shr:1 leaves lane 0 of the destination alone);
+        // the windows then move up by one lane (wave_rol:1).  No SGPR round trip (v_readlane + v_mov
+        // cost the lone wave ~12 cycles each).
+        // (mov_dpp = no "old" operand tied to the destination: the rotation needs no copy of the window)
+        const uint32_t next_left = __builtin_amdgcn_mov_dpp(win_left, 0x134 /* wave_rol:1 */, 0xF, 0xF, true);
+        const uint32_t next_b = __builtin_amdgcn_mov_dpp(win_b, 0x134, 0xF, 0xF, true);
+        uint32_t left = __builtin_amdgcn_update_dpp(win_left, last, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        bc = __builtin_amdgcn_update_dpp(win_b, bc, 0x138, 0xF, 0xF, false);
+        win_left = next_left;
+        win_b = next_b;
         if (active) {
             uint32_t diag_v = diag_in;
             diag_in = left;
@@ -175,12 +182,12 @@ __global__ __launch_bounds__(64) void ed_band_kernel(const EdBandArgs a)
         // out_lane has just finished row s - out_lane: rotate the collector by one lane and drop the new
         // value in at out_lane, so the row finished t steps ago sits t lanes below it (all lanes enabled;
         // a step in which out_lane has no row collects a value that is never handed over)
-        const uint32_t rot = __builtin_amdgcn_update_dpp(acc, acc, 0x134 /* wave_rol:1 */, 0xF, 0xF, false);
+        const uint32_t rot = __builtin_amdgcn_mov_dpp(acc, 0x134 /* wave_rol:1 */, 0xF, 0xF, true);
         acc = is_out ? outv : rot;
     };
-    // keep the part of the window that rows [first, first + G) live in
-    auto merge = [&](uint32_t &win, uint32_t fresh, uint32_t first) {
-        const bool mine = lane / G == (first / G) % (64u / G);
+    // rows [s0 + G, s0 + 2G) go to lanes [G, 2G) of a window at boundary s0 (`upper`), the very first group to [0, G)
+    auto merge = [&](uint32_t &win, uint32_t fresh, bool upper) {
+        const bool mine = lane / G == (upper ? 1u : 0u);
         win = mine ? fresh : win;
     };
 
@@ -192,8 +199,8 @@ __global__ __launch_bounds__(64) void ed_band_kernel(const EdBandArgs a)
         // the next group's prefetch is in flight (hipcc would put a vmcnt(0) at the first use of ac[])
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
         const uint32_t v0 = validate(load_left(0), 0);
-        merge(win_left, v0, 0);
-        merge(win_b, (uint32_t)load_b(0), 0);
+        merge(win_left, v0, false);
+        merge(win_b, (uint32_t)load_b(0), false);
         if (!failed) {
             nxt_left = load_left(G);
             nxt_b = load_b(G);
@@ -218,8 +225,8 @@ __global__ __launch_bounds__(64) void ed_band_kernel(const EdBandArgs a)
         // rows [s0 + G, s0 + 2G): requested one boundary ago, needed from the next boundary on
         const uint32_t fresh = validate(nxt_left, s0 + G);
         if (failed) break;
-        merge(win_left, fresh, s0 + G);
-        merge(win_b, (uint32_t)nxt_b, s0 + G);
+        merge(win_left, fresh, true);
+        merge(win_b, (uint32_t)nxt_b, true);
         // a use the compiler can see: its wait for the merged values lands HERE, before the next
         // request is issued, instead of as a vmcnt(0) at their first use inside the step loop
         asm volatile("" : "+v"(win_left), "+v"(win_b));

@@ -553,7 +553,7 @@ constexpr int ED_TILES = 32;         // flag: tiles from both corners (one launc
 constexpr int ED_FLAGS = ED_ONE_DIRECTION | ED_TILES;
 constexpr uint64_t ED_BAND_WS_LIMIT = 16ull << 30; // bytes of right-column storage the band pipeline may take
 constexpr uint64_t ED_BAND_WS_KEEP = 1ull << 30;   // workspaces up to this size stay in the context between calls
-constexpr int ED_BAND_LAG = 160;                   // rows a band trails its predecessor by (measured; sets the cut rows)
+constexpr int ED_BAND_LAG = 180;                   // rows a band trails its predecessor by (measured; sets the cut rows)
 
 // Band pipeline (bmx_ed_band_kernel.h).  Returns BMX_OK with *used = false if it does not apply
 // (workspace too large / allocation refused): the caller then takes the tile schedule.
