@@ -179,7 +179,8 @@ int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6]);
  * launch, 8 words per wave {issue, walk, dma_wait, barrier_wait, tiles, 0, 0, 0}.
  * Returns the number of words copied. */
 int bmx_scan_stamps(bmx_ctx *ctx, uint64_t *out, uint64_t max_words);
-/* Tuning knob for experiments: 0 = default kernel variant. */
+/* Tuning knob for experiments: -1 = automatic choice (the state of a new context: the default
+ * kernel, or the 4-gram walker for patterns over at most 8 distinct symbols), >= 0 = that kernel. */
 int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu);
 
 /* ---- edit distance: the reference's second algorithm ------------ */

@@ -94,10 +94,13 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint
     }
 }
 
+constexpr uint32_t QGRAM_TABLE = 4096; // entries of the 4-gram shift table (u32 in LDS: 16 KiB)
+
 struct LdsTables {
     const uint16_t *bad;  // 256 x u16 (entry of the pattern's last character: 0 if SKIP)
     const uint16_t *good; // m x u16
     const uint8_t *pat;   // m bytes
+    const uint32_t *qtab; // QGRAM_TABLE x u32, 4-gram walker only
     uint32_t m;
     // scalar copies for the skip-loop walker
     uint32_t b_last, p3, g1, g2, g3;
@@ -174,6 +177,56 @@ __device__ __forceinline__ void walk_lane(const ScanArgs &a, const LdsTables &tb
     }
 }
 
+// ---- 4-gram walker --------------------------------------------------------------------------
+// The reference's bad-symbol rule looks at ONE text character (the window's last) and shifts so
+// that it meets its right-most occurrence in the pattern (BoyreMoore.cpp:151-162, kernel1.cl:27-28).
+// On a 4-letter alphabet every character occurs within the last few pattern positions, shifts are
+// 3-5 bytes and the scan is bound by the walkers.  The same rule on the
+// window's last FOUR characters (Wu-Manber / Zhu-Takaoka style): qtab[h(g)] = m-1-j for the
+// right-most pattern position j at which a 4-gram with hash h(g) ends, m-3 if there is none.  Any
+// occurrence of the pattern that overlaps text[i-3..i] aligns that 4-gram with an equal one of the
+// pattern, so no occurrence ends before i + qtab[h]: the shift is safe, hash collisions only make
+// it smaller.  qtab == 0 means "the window may end in the pattern's last 4-gram": it is verified
+// right to left exactly like the reference does (kernel1.cl:20-24) and left with the reference's own
+// shift (:27-33).  The match list is therefore the same; only the sequence of windows visited
+// differs, which nothing observes.
+__device__ __forceinline__ uint32_t qgram_hash(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3)
+{
+    const uint32_t w = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    return (w * 0x9E3779B1u) >> 20; // 12 bits
+}
+
+__device__ __forceinline__ void walk_lane_qgram(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
+                                                uint32_t hi, uint64_t tile_off)
+{
+    const uint32_t m = tb.m; // >= 4
+    uint32_t i = lo + m - 1;
+    const uint32_t ilim = hi + m - 1;
+    while (i < ilim) {
+        // text[i-3..i] as one word: the two aligned dwords that hold it (one ds_read2_b32; the second may
+        // reach up to 4 bytes past the window, never past the workgroup's LDS) and v_alignbyte
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(T + ((i - 3) & ~3u));
+        const uint32_t w = __builtin_amdgcn_alignbyte(p[1], p[0], (i - 3) & 3u);
+        const uint32_t s = tb.qtab[(w * 0x9E3779B1u) >> 20];
+        if (s != 0) {
+            i += s;
+            continue;
+        }
+        uint32_t k = 0; // kernel1.cl:20-22
+        while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+        if (k == m) { // kernel1.cl:24
+            const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
+            emit_hit(a, astart - a.first, astart + a.out_bias);
+            i += 1;
+            continue;
+        }
+        const int b = (int)tb.bad[T[i]];
+        const int d1 = b - (int)k > 1 ? b - (int)k : 1;                  // kernel1.cl:28
+        const int d2 = (int)tb.good[k];                                   // kernel1.cl:29
+        i += (uint32_t)(k == 0 ? d1 : (d1 > d2 ? d1 : d2));               // kernel1.cl:30-33
+    }
+}
+
 // wait until at most n of this wave's vector-memory operations are outstanding
 __device__ __forceinline__ void wait_vmcnt_at_most(uint32_t n)
 {
@@ -196,7 +249,7 @@ __device__ __forceinline__ void wait_vmcnt_at_most(uint32_t n)
 // >= 0x80 cannot occur in an ASCII pattern: their entry is the full shift m.  The scalars
 // are forced through readfirstlane HERE: a load still pending when the walk first uses it
 // would cost an s_waitcnt vmcnt(0) that also drains the LDS-DMA in flight.
-template <bool SKIP>
+template <bool SKIP, bool QGRAM = false>
 __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *base, uint32_t tid, uint32_t nthreads)
 {
     const uint32_t m = a.m;
@@ -217,6 +270,16 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
     tb.bad = s_bad;
     tb.good = s_good;
     tb.pat = s_pat;
+    tb.qtab = nullptr;
+    if (QGRAM) { // every thread of the workgroup is here (two barriers)
+        uint32_t *s_q = reinterpret_cast<uint32_t *>(s_pat + ((m + 15) & ~15u));
+        for (uint32_t i = tid; i < QGRAM_TABLE; i += nthreads) s_q[i] = m - 3;
+        __syncthreads();
+        for (uint32_t j = 3 + tid; j < m; j += nthreads) // right-most end position wins: the minimum of m-1-j
+            atomicMin(&s_q[qgram_hash(a.tab.pat[j - 3], a.tab.pat[j - 2], a.tab.pat[j - 1], a.tab.pat[j])], m - 1 - j);
+        __syncthreads();
+        tb.qtab = s_q;
+    }
     tb.m = m;
     tb.m4 = m >= 4;
     tb.b_last = tb.p3 = tb.g1 = tb.g2 = tb.g3 = 0;

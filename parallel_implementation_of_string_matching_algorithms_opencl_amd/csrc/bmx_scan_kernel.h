@@ -36,7 +36,8 @@ namespace bmx {
 // MODE 0 is the product; MODE 1 (DMA only, no walkers) and MODE 2 (walkers only:
 // each workgroup loads its first two tiles and keeps re-walking them) exist for
 // timing the two halves alone and return wrong match lists.
-// WALK 0: byte-wise walker, any m.  WALK 2: skip-loop walker, needs m >= 4.
+// WALK 0: byte-wise walker, any m.  WALK 2: skip-loop walker, needs m >= 4.  WALK 3: 4-gram
+// walker (bmx_scan_common.h), needs m >= 4 and 16 KiB more LDS.
 // (A WALK 1 that fetched the last four characters with one unaligned ds_read_b32 was
 // 35 % slower -- unaligned LDS dwords -- and is gone)
 // LOADERS: 0 = every wave issues its share of the tile DMA and then walks.
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lane = tid & 63;
-    const LdsTables tb = load_tables<WALK == 2>(a, smem + 2 * buf_bytes, tid, BLOCK);
+    const LdsTables tb = load_tables<WALK == 2, WALK == 3>(a, smem + 2 * buf_bytes, tid, BLOCK);
 
     const uint32_t nchunk = buf_bytes >> 4; // 16-B chunks per tile incl. halo
     auto issue_tile = [&](uint64_t t, uint8_t *dst) {
@@ -137,8 +138,12 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
         const uint64_t rem = a.own_end - tile_off; // > 0 because t < tile_end
         if (rem < (uint64_t)hi) hi = (uint32_t)rem;
 
-        if (MODE != 1 && !is_loader && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi)
-            walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
+        if (MODE != 1 && !is_loader && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi) {
+            if constexpr (WALK == 3)
+                walk_lane_qgram(a, tb, T, lo, hi, tile_off);
+            else
+                walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
+        }
         if (MODE == 5) {
             const unsigned long long x = stamp();
             st_walk += x - st_prev;

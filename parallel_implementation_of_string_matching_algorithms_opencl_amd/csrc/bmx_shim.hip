@@ -68,18 +68,19 @@ struct Variant {
     int nbuf;
     int loaders; // kind 0: waves that only issue DMA
     bool stamps; // diagnostic build that writes s_memtime sums (bmx_scan_stamps)
+    bool qgram;  // 4-gram walker: 16 KiB shift table in LDS, needs the canonical shift tables
     void (*kernel)(const bmx::ScanArgs);
     void (*kernel_short)(const bmx::ScanArgs);
 };
 
 #define BMX_TILE(B, S, AUX, MODE, W) BMX_TILE_L(B, S, AUX, MODE, W, 0)
 #define BMX_TILE_L(B, S, AUX, MODE, W, L) \
-    {0, B, S, 2, L, (MODE) == 5, bmx::scan_kernel<B, S, AUX, MODE, W, L>, bmx::scan_kernel<B, S, AUX, MODE, 0, L>}
+    {0, B, S, 2, L, (MODE) == 5, (W) == 3, bmx::scan_kernel<B, S, AUX, MODE, W, L>, bmx::scan_kernel<B, S, AUX, MODE, 0, L>}
 #define BMX_RING(B, S, AUX, SKIP, MODE) BMX_RING_P(B, S, AUX, SKIP, MODE, 0)
 #define BMX_RING_P(B, S, AUX, SKIP, MODE, P) \
-    {2, B, S, 3, 0, (MODE) == 5, bmx::scan_ring_kernel<B, S, AUX, SKIP, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, false, MODE, P>}
+    {2, B, S, 3, 0, (MODE) == 5, false, bmx::scan_ring_kernel<B, S, AUX, SKIP, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, false, MODE, P>}
 #define BMX_WAVE(WV, S, AUX, MODE, D, NB)                                                      \
-    {1, (WV) * 64, S, NB, 0, false, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>}
+    {1, (WV) * 64, S, NB, 0, false, false, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>}
 const Variant g_variants[] = {
     // ---- products (every one parity-tested by tests/test_gpu_parity.py) ----
     BMX_TILE(1024, 68, 2, 0, 0),        // 0: default -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
@@ -109,6 +110,8 @@ const Variant g_variants[] = {
     BMX_TILE(512, 76, 2, 0, 0),         // 21: same, 38 KiB tiles
     BMX_TILE(512, 132, 2, 0, 0),        // 22: one workgroup of 8 waves, 66 KiB tiles
     BMX_TILE(1024, 36, 2, 0, 0),        // 23: variant 2's geometry with the byte-wise walker
+    BMX_TILE(1024, 68, 2, 0, 3),        // 24: default geometry, 4-gram walker (picked automatically for small alphabets)
+    BMX_TILE(1024, 36, 2, 0, 3),        // 25: 4-gram walker, 36 KiB tiles, two workgroups per CU
 };
 constexpr int N_PRODUCT_VARIANTS = 12;
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
@@ -159,7 +162,8 @@ uint64_t unit_bytes(const Variant &v)
 uint32_t lds_bytes_for(const Variant &v, int32_t m)
 {
     const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
-    const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u);
+    const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u) +
+                            (v.qgram ? bmx::QGRAM_TABLE * 4u : 0u);
     if (v.kind != 1) return (uint32_t)v.nbuf * ((uint32_t)unit_bytes(v) + halo16) + tables;
     return (uint32_t)(v.block / 64) * v.nbuf * (64u * v.seg + halo16) + tables;
 }
@@ -174,19 +178,26 @@ int blocks_per_cu_for(const bmx_ctx *ctx, const Variant &v, int32_t m)
 }
 
 // Default kernel choice.  On small alphabets (DNA: 4 symbols) almost every window ends in
-// a character of the pattern and shifts are a few bytes: the walkers, not HBM, bound the
-// scan.  There the skip-loop walker is 1.7x faster than the byte-wise one and twice the
-// waves per CU (two workgroups on 36 KiB tiles) another 1.2x (4 GiB ACGT, m = 64:
-// 1.2 -> 2.0 -> 2.3-2.4 TB/s); a "quad" walker (text[i-3..i] by one aligned ds_read2_b32 +
-// v_alignbyte, k from XOR/clz) tied with it and a two-streams-per-lane version of that was
-// 40 % slower, so neither is kept.  On wide alphabets the byte-wise walker on 68 KiB tiles
-// is ahead.  The text is unknown here, the pattern's own alphabet is the hint.
+// a character of the pattern and the reference's one-character bad-symbol rule shifts by a few
+// bytes: the walkers, not HBM, bound the scan (4 GiB ACGT, m = 64: 1.2 TB/s byte-wise walker,
+// 2.0 skip loop, 2.3 skip loop + two workgroups per CU = variant 2).  The 4-gram walker
+// (walk_lane_qgram: the same rule on the window's last four characters) shifts by ~50 and
+// reaches 5.7 TB/s on the default geometry; it needs the canonical shift tables (below).
 uint32_t lds_bytes_for(const Variant &v, int32_t m);
 
-int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m)
+constexpr int VARIANT_QGRAM = 24;
+
+// `canonical`: the shift tables in use are the ones bmx_build_tables makes (always so when the caller
+// passes none).  The 4-gram walker skips with its own table and only leaves a verified window with
+// the caller's shifts, so with tables that shift FURTHER than the canonical ones (unsafe ones: the
+// reference kernel would miss matches) it would not reproduce the reference kernel's list.
+int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical)
 {
-    if (!ctx->auto_walker) // an explicitly chosen variant whose buffers + halo do not fit at this m
-        return lds_bytes_for(g_variants[ctx->variant], m) <= LDS_PER_CU ? ctx->variant : 0; // -> default
+    if (!ctx->auto_walker) { // an explicitly chosen variant
+        const Variant &v = g_variants[ctx->variant];
+        if (v.qgram && !canonical) return 2;
+        return lds_bytes_for(v, m) <= LDS_PER_CU ? ctx->variant : 0; // buffers + halo do not fit at this m -> default
+    }
     if (m < 4) return 0;
     bool seen[256] = {};
     int distinct = 0;
@@ -195,20 +206,25 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m)
             seen[(unsigned char)pat[i]] = true;
             ++distinct;
         }
-    return distinct <= 8 ? 2 : 0;
+    if (distinct > 8) return 0;
+    return canonical && m >= 8 && lds_bytes_for(g_variants[VARIANT_QGRAM], m) <= LDS_PER_CU ? VARIANT_QGRAM : 2;
 }
 
 // Convert the caller's int32 tables (or build them) into the kernel-argument layout.
-int fill_tables(bmx::ScanTables &tab, const char *pat, int32_t m, const int32_t *good, const int32_t *bad)
+int fill_tables(bmx::ScanTables &tab, const char *pat, int32_t m, const int32_t *good, const int32_t *bad,
+                bool *canonical)
 {
-    std::vector<int32_t> own_good;
+    std::vector<int32_t> own_good(m);
     int32_t own_bad[BMX_BAD_TABLE_SIZE];
+    int rc = bmx_build_tables(pat, m, own_bad, own_good.data());
+    if (rc != BMX_OK) return rc;
+    *canonical = true;
     if (!good || !bad) {
-        own_good.resize(m);
-        int rc = bmx_build_tables(pat, m, own_bad, own_good.data());
-        if (rc != BMX_OK) return rc;
         good = own_good.data();
         bad = own_bad;
+    } else { // the caller's tables (like the reference passes its own): are they the canonical ones?
+        for (int c = 0; c < BMX_BAD_TABLE_SIZE && *canonical; ++c) *canonical = bad[c] == own_bad[c];
+        for (int k = 1; k < m && *canonical; ++k) *canonical = good[k] == own_good[k]; // good[0] is never read
     }
     // kernel1.cl:28 clamps (bad - k) to >= 1, and k == 0 uses bad as is
     for (int i = 0; i < m; ++i) // the kernels index 128-entry tables with pattern characters
@@ -294,7 +310,13 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
 
 int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu)
 {
-    if (!ctx || variant < 0 || variant >= N_VARIANTS || blocks_per_cu < 0) return BMX_ERR_ARG;
+    if (!ctx || variant < -1 || variant >= N_VARIANTS || blocks_per_cu < 0) return BMX_ERR_ARG;
+    if (variant == -1) { // back to the automatic choice (pick_variant)
+        ctx->variant = 0;
+        ctx->auto_walker = true;
+        ctx->blocks_per_cu = blocks_per_cu;
+        return BMX_OK;
+    }
     (void)N_PRODUCT_VARIANTS; // variants >= N_PRODUCT_VARIANTS exist for tools/variant_sweep.py only
     ctx->variant = variant;
     ctx->auto_walker = false;
@@ -358,19 +380,20 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     uint64_t *out = capacity ? d_match_positions : nullptr;
 
     if (n_starts > 0) {
-        const int vi = pick_variant(ctx, pat, m);
+        bmx::ScanArgs a;
+        bool canonical = true;
+        int rc = fill_tables(a.tab, pat, m, good, bad, &canonical);
+        if (rc != BMX_OK) {
+            ctx->armed = true; // nothing was launched
+            return rc;
+        }
+        const int vi = pick_variant(ctx, pat, m, canonical);
         ctx->last_variant = vi;
         const Variant &v = g_variants[vi];
         const uint64_t tile = unit_bytes(v);
         const uintptr_t addr = (uintptr_t)d_text;
         const uint64_t mis = addr & 15u;
 
-        bmx::ScanArgs a;
-        int rc = fill_tables(a.tab, pat, m, good, bad);
-        if (rc != BMX_OK) {
-            ctx->armed = true; // nothing was launched
-            return rc;
-        }
         a.text16 = (const uint8_t *)(addr - mis);
         a.first = mis;
         a.own_end = mis + n_starts;

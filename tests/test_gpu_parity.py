@@ -14,7 +14,8 @@ from parallel_implementation_of_string_matching_algorithms_opencl_amd import cor
 
 pytestmark = pytest.mark.gpu
 
-N_VARIANTS = 12  # bmx_shim.hip: variants 0..11 are products, the rest timing experiments
+PRODUCT_VARIANTS = list(range(12)) + [20, 21, 22, 23, 24, 25]  # bmx_shim.hip: the others are timing experiments
+QGRAM_VARIANTS = [24, 25]  # 4-gram walker
 
 
 def sha(a):
@@ -84,7 +85,7 @@ def test_ranges_golden_reference_kernel_contract(ctx, port):
 def test_random_texts_vs_oracle_all_variants(ctx, port):
     rng = np.random.default_rng(2026)
     try:
-        for v in range(N_VARIANTS):
+        for v in PRODUCT_VARIANTS:
             ctx.set_variant(v)
             for _ in range(12):
                 alpha = int(rng.integers(1, 6))
@@ -96,6 +97,46 @@ def test_random_texts_vs_oracle_all_variants(ctx, port):
                 got = dev_search(ctx, text, pat)
                 want = port.search(text, pat)
                 assert np.array_equal(got, want), (v, n, m, alpha)
+    finally:
+        ctx.set_variant(0)
+
+
+def test_four_gram_walker_vs_oracle(ctx, port):
+    """The 4-gram walker (picked automatically for small alphabets; here also forced onto large
+    ones, where its hash table has collisions): periodic and self-overlapping patterns, hits at
+    every distance, m around 4 (below 4 the byte-wise walker takes over), long patterns."""
+    rng = np.random.default_rng(424)
+    try:
+        for v in QGRAM_VARIANTS + [-1]:
+            ctx.set_variant(v)  # -1: the automatic choice
+            for case in range(40):
+                alpha = int(rng.choice([1, 2, 3, 4, 4, 4, 20, 95]))
+                m = int(rng.choice([1, 3, 4, 5, 7, 8, 9, 16, 31, 64, 99, 200, 512]))
+                n = int(rng.integers(m, 400000))
+                text = (rng.integers(0, alpha, n) + 33).astype(np.uint8)
+                kind = case % 4
+                if kind == 0:  # pattern taken from the text
+                    a = int(rng.integers(0, n - m + 1))
+                    pat = text[a:a + m].copy()
+                elif kind == 1:  # periodic pattern, planted back to back (overlapping hits)
+                    unit = (rng.integers(0, alpha, int(rng.integers(1, 5))) + 33).astype(np.uint8)
+                    pat = np.resize(unit, m)
+                    a = int(rng.integers(0, max(1, n - 3 * m)))
+                    text[a:a + min(3 * m, n - a)] = np.resize(unit, min(3 * m, n - a))
+                elif kind == 2:  # random pattern, planted at random places
+                    pat = (rng.integers(0, alpha, m) + 33).astype(np.uint8)
+                    for p in rng.integers(0, n - m + 1, 30):
+                        text[p:p + m] = pat
+                else:  # a pattern that differs from the text only in its FIRST character
+                    a = int(rng.integers(0, n - m + 1))
+                    pat = text[a:a + m].copy()
+                    pat[0] = 33 + (pat[0] - 33 + 1) % max(alpha, 2)
+                got = dev_search(ctx, text, pat.tobytes())
+                assert np.array_equal(got, port.search(text, pat.tobytes())), (v, alpha, m, n, kind)
+            if v < 0:  # the automatic choice on DNA is the 4-gram walker
+                t = (rng.integers(0, 4, 100000) + 65).astype(np.uint8)
+                dev_search(ctx, t, t[50:114].tobytes())
+                assert ctx.geometry(64)["lds_bytes"] > 150000
     finally:
         ctx.set_variant(0)
 
@@ -121,7 +162,7 @@ def test_hit_at_every_offset_around_tile_and_segment_boundaries(ctx, port):
     m = 16
     pat = b"Q" * 15 + b"R"
     try:
-        for v in range(N_VARIANTS):
+        for v in PRODUCT_VARIANTS:
             ctx.set_variant(v)
             g = ctx.geometry(m)
             tile, seg = g["tile_bytes"], g["seg"]
@@ -278,6 +319,18 @@ def test_caller_tables_are_used_like_the_reference_kernel_uses_them(ctx, port):
     good = np.ones(12, dtype=np.int32)
     assert np.array_equal(dev_search(ctx, text, pat, tables=(bad, good)), want)
     assert np.array_equal(dev_search(ctx, text, pat, tables=port.tables(pat)), want)
+    # UNSAFE tables (shifts larger than the pattern allows): the reference kernel then misses
+    # matches, and so must this one -- the 4-gram walker, which would find them all, steps aside
+    bad2 = np.full(128, 12, dtype=np.int32)
+    good2 = np.full(12, 12, dtype=np.int32)
+    try:
+        ctx.set_variant(24)
+        got2 = dev_search(ctx, text, pat, tables=(bad2, good2))
+        ctx.set_variant(2)
+        assert np.array_equal(got2, dev_search(ctx, text, pat, tables=(bad2, good2)))
+        assert got2.size < want.size  # windows were skipped, as the reference kernel would
+    finally:
+        ctx.set_variant(0)
 
 
 def test_device_generator_matches_host_generator(ctx):
