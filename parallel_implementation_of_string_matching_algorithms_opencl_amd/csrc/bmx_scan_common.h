@@ -101,6 +101,7 @@ struct LdsTables {
     const uint16_t *good; // m x u16
     const uint8_t *pat;   // m bytes
     const uint32_t *qtab; // QGRAM_TABLE x u32, 4-gram walker only
+    const uint8_t *bad8;  // 256 x u8 copy of bad[] (m <= 255): 64 LDS words = 2 per bank instead of 4
     uint32_t m;
     // scalar copies for the skip-loop walker
     uint32_t b_last, p3, g1, g2, g3;
@@ -227,6 +228,78 @@ __device__ __forceinline__ void walk_lane_qgram(const ScanArgs &a, const LdsTabl
     }
 }
 
+// ---- byte-wise walker on the 8-bit copy of the bad-symbol table (m <= 255) ------------------
+__device__ __forceinline__ void walk_lane_b8(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
+                                             uint32_t hi, uint64_t tile_off)
+{
+    const uint32_t m = tb.m;
+    uint32_t i = lo + m - 1;
+    const uint32_t ilim = hi + m - 1;
+    const uint32_t plast = tb.pat[m - 1];
+    while (i < ilim) {
+        const uint32_t c = T[i];
+        const uint32_t b = tb.bad8[c];
+        if (c != plast) {
+            i += b;
+            continue;
+        }
+        uint32_t k = 1;
+        while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+        if (k == m) {
+            const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
+            emit_hit(a, astart - a.first, astart + a.out_bias);
+            i += 1;
+            continue;
+        }
+        const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1;
+        const int d2 = (int)tb.good[k];
+        i += (uint32_t)(d1 > d2 ? d1 : d2);
+    }
+}
+
+// ---- byte-wise walker, two windows in flight -----------------------------------------------
+// The walk is a chain of dependent LDS reads (text byte -> shift -> next text byte).  On a large
+// alphabet most windows end in a character that is not in the pattern and shift by the full m
+// (printable-95, m = 16: 83 %), so the window after next is usually the one at i + m: its last
+// character and shift are read TOGETHER with the current ones and used when the guess was right.
+// Same windows, same shifts as walk_lane<false>; only the order of the LDS reads differs.
+__device__ __forceinline__ void walk_lane_spec(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
+                                               uint32_t hi, uint64_t tile_off)
+{
+    const uint32_t m = tb.m;
+    uint32_t i = lo + m - 1;
+    const uint32_t ilim = hi + m - 1;
+    const uint32_t plast = tb.pat[m - 1];
+    while (i < ilim) {
+        uint32_t c = T[i];
+        const uint32_t c2 = T[i + m]; // may lie past this lane's windows (never past the workgroup's LDS): unused then
+        uint32_t b = tb.bad[c];
+        const uint32_t b2 = tb.bad[c2];
+        if (c != plast) { // k == 0: shift = bad[c] (kernel1.cl:28,30)
+            i += b;
+            if (b != m || i >= ilim) continue;
+            // the guess was right: the window at i is the one whose last character is c2
+            if (c2 != plast) {
+                i += b2;
+                continue;
+            }
+            c = c2;
+            b = b2;
+        }
+        uint32_t k = 1; // kernel1.cl:20-22
+        while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+        if (k == m) { // kernel1.cl:24
+            const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
+            emit_hit(a, astart - a.first, astart + a.out_bias);
+            i += 1;
+            continue;
+        }
+        const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28
+        const int d2 = (int)tb.good[k];                             // kernel1.cl:29
+        i += (uint32_t)(d1 > d2 ? d1 : d2);                         // kernel1.cl:31
+    }
+}
+
 // wait until at most n of this wave's vector-memory operations are outstanding
 __device__ __forceinline__ void wait_vmcnt_at_most(uint32_t n)
 {
@@ -270,9 +343,15 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
     tb.bad = s_bad;
     tb.good = s_good;
     tb.pat = s_pat;
+    uint8_t *s_bad8 = s_pat + ((m + 15) & ~15u);
+    for (uint32_t i = tid; i < 256; i += nthreads) {
+        const uint32_t v = i < 128 ? a.tab.bad[i] : m;
+        s_bad8[i] = (uint8_t)(v < 255 ? v : 255);
+    }
+    tb.bad8 = s_bad8;
     tb.qtab = nullptr;
     if (QGRAM) { // every thread of the workgroup is here (two barriers)
-        uint32_t *s_q = reinterpret_cast<uint32_t *>(s_pat + ((m + 15) & ~15u));
+        uint32_t *s_q = reinterpret_cast<uint32_t *>(s_bad8 + 256);
         for (uint32_t i = tid; i < QGRAM_TABLE; i += nthreads) s_q[i] = m - 3;
         __syncthreads();
         for (uint32_t j = 3 + tid; j < m; j += nthreads) // right-most end position wins: the minimum of m-1-j

@@ -37,7 +37,8 @@ namespace bmx {
 // each workgroup loads its first two tiles and keeps re-walking them) exist for
 // timing the two halves alone and return wrong match lists.
 // WALK 0: byte-wise walker, any m.  WALK 2: skip-loop walker, needs m >= 4.  WALK 3: 4-gram
-// walker (bmx_scan_common.h), needs m >= 4 and 16 KiB more LDS.
+// walker (bmx_scan_common.h), needs m >= 4 and 16 KiB more LDS.  WALK 4: byte-wise walker with two
+// windows in flight.
 // (A WALK 1 that fetched the last four characters with one unaligned ds_read_b32 was
 // 35 % slower -- unaligned LDS dwords -- and is gone)
 // LOADERS: 0 = every wave issues its share of the tile DMA and then walks.
@@ -141,6 +142,10 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
         if (MODE != 1 && !is_loader && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi) {
             if constexpr (WALK == 3)
                 walk_lane_qgram(a, tb, T, lo, hi, tile_off);
+            else if constexpr (WALK == 4)
+                walk_lane_spec(a, tb, T, lo, hi, tile_off);
+            else if constexpr (WALK == 5)
+                walk_lane_b8(a, tb, T, lo, hi, tile_off);
             else
                 walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
         }

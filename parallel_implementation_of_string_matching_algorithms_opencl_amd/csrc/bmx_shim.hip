@@ -112,6 +112,8 @@ const Variant g_variants[] = {
     BMX_TILE(1024, 36, 2, 0, 0),        // 23: variant 2's geometry with the byte-wise walker
     BMX_TILE(1024, 68, 2, 0, 3),        // 24: default geometry, 4-gram walker (picked automatically for small alphabets)
     BMX_TILE(1024, 36, 2, 0, 3),        // 25: 4-gram walker, 36 KiB tiles, two workgroups per CU
+    BMX_TILE(1024, 68, 2, 0, 4),        // 26: default geometry, byte-wise walker with two windows in flight
+    BMX_TILE(1024, 68, 2, 0, 5),        // 27: byte-wise walker on an 8-bit bad-symbol table (m <= 255 only)
 };
 constexpr int N_PRODUCT_VARIANTS = 12;
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
@@ -162,7 +164,7 @@ uint64_t unit_bytes(const Variant &v)
 uint32_t lds_bytes_for(const Variant &v, int32_t m)
 {
     const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
-    const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u) +
+    const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u) + 256 +
                             (v.qgram ? bmx::QGRAM_TABLE * 4u : 0u);
     if (v.kind != 1) return (uint32_t)v.nbuf * ((uint32_t)unit_bytes(v) + halo16) + tables;
     return (uint32_t)(v.block / 64) * v.nbuf * (64u * v.seg + halo16) + tables;
