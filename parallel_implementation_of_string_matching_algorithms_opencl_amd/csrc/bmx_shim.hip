@@ -209,7 +209,7 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical)
             ++distinct;
         }
     if (distinct > 8) return 0;
-    return canonical && m >= 8 && lds_bytes_for(g_variants[VARIANT_QGRAM], m) <= LDS_PER_CU ? VARIANT_QGRAM : 2;
+    return canonical && m >= 10 && lds_bytes_for(g_variants[VARIANT_QGRAM], m) <= LDS_PER_CU ? VARIANT_QGRAM : 2;
 }
 
 // Convert the caller's int32 tables (or build them) into the kernel-argument layout.
