@@ -48,10 +48,12 @@ struct ScanArgs {
     unsigned long long *stamps; // MODE 5 only (diagnostic build): per-wave cycle sums, 8 words per wave
     uint32_t m;
     uint32_t halo16;         // (m-1) rounded up to a multiple of 16
+    uint32_t stage_cap;      // matches a wave can park in LDS per tile before it appends to HBM (0: none)
     ScanTables tab;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
+typedef volatile __attribute__((address_space(3))) uint32_t lds_u32; // explicit LDS accesses (ds_*), never flat_*
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 __device__ __forceinline__ lds_void *to_lds(const void *p)
@@ -102,11 +104,90 @@ struct LdsTables {
     const uint8_t *pat;   // m bytes
     const uint32_t *qtab; // QGRAM_TABLE x u32, 4-gram walker only
     const uint8_t *bad8;  // 256 x u8 copy of bad[] (m <= 255): 64 LDS words = 2 per bank instead of 4
+    lds_u32 *stage;       // this wave's parking area for matches: tile-local window starts
+    lds_u32 *stage_cnt;   // how many it holds (may run past stage_cap: the excess went straight to HBM)
+    uint32_t stage_cap;
     uint32_t m;
     // scalar copies for the skip-loop walker
     uint32_t b_last, p3, g1, g2, g3;
     bool m4;
 };
+
+// A match found by a walker (called under divergence).  Appending to HBM costs a global atomic with
+// its round trip INSIDE the walk loop (and hipcc drains the LDS-DMA in flight with it): fine for one
+// match per MiB, a cliff for dense results (1 GiB printable text, m = 1: 12.6 M matches took 107 ms).
+// So a wave parks its matches of the current tile in LDS (one LDS atomic per call) and appends them
+// together once it has walked the tile (flush_stage); what does not fit goes the direct way.
+__device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &tb, uint64_t astart, uint64_t tile_off)
+{
+    if (tb.stage_cap != 0) { // wave-uniform
+        const uint64_t active = __ballot(1);
+        const uint32_t lane = __lane_id();
+        const int leader = __ffsll((unsigned long long)active) - 1;
+        const uint32_t rank = __popcll(active & ((1ull << lane) - 1ull));
+        // the counter is this wave's alone and the wave runs this sequence one divergent branch at a time:
+        // a plain read-modify-write by the leader, through volatile so that no lane keeps a stale copy in a
+        // register (an LDS ATOMIC here makes hipcc drain vmcnt first, i.e. wait for the tile DMA in flight)
+        lds_u32 *cnt = tb.stage_cnt;
+        uint32_t base = 0;
+        if ((int)lane == leader) {
+            base = *cnt;
+            *cnt = base + (uint32_t)__popcll(active);
+        }
+        base = __shfl(base, leader);
+        if (base + rank < tb.stage_cap) {
+            tb.stage[base + rank] = (uint32_t)(astart - tile_off);
+            return;
+        }
+    }
+    emit_hit(a, astart - a.first, astart + a.out_bias);
+}
+
+// The whole wave, after its walk of a tile: append the parked matches (one global atomic per 64) and
+// enter them into their position buckets (one atomic per distinct bucket among 64 matches).
+__device__ __forceinline__ void flush_stage(const ScanArgs &a, const LdsTables &tb, uint64_t tile_off)
+{
+    if (tb.stage_cap == 0) return;
+    const uint32_t lane = __lane_id();
+    lds_u32 *cnt_p = tb.stage_cnt;
+    uint32_t n = __builtin_amdgcn_readfirstlane(*cnt_p);
+    if (n == 0) return;
+    if (lane == 0) *cnt_p = 0;
+    n = n < tb.stage_cap ? n : tb.stage_cap;
+    // once a bucket has overflowed the list is ordered by a sort anyway: stop feeding the buckets
+    const bool buckets = a.out != nullptr && __builtin_amdgcn_readfirstlane(*a.bucket_overflow) == 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool valid = j < n;
+        const uint64_t astart = tile_off + (valid ? tb.stage[j] : 0u);
+        const uint64_t pos = astart + a.out_bias;
+        const uint32_t cnt = n - j0 < 64 ? n - j0 : 64;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.count, (unsigned long long)cnt);
+        base = __shfl(base, 0);
+        if (a.out == nullptr) continue;
+        if (valid && base + lane < a.cap) a.out[base + lane] = pos;
+        if (!buckets) continue;
+        const uint32_t b = (uint32_t)((astart - a.first) >> a.bucket_shift);
+        uint64_t todo = __ballot(valid);
+        while (todo != 0) { // wave-uniform: one round per distinct bucket
+            const int l0 = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t b0 = __shfl(b, l0);
+            const uint64_t same = __ballot(valid && b == b0) & todo;
+            uint32_t s0 = 0;
+            if ((int)lane == l0) s0 = atomicAdd(&a.bucket_cnt[b0], (uint32_t)__popcll(same));
+            s0 = __shfl(s0, l0);
+            if ((same >> lane) & 1ull) {
+                const uint32_t slot = s0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                if (slot < (uint32_t)ORDER_BUCKET_CAP)
+                    a.bucket_store[(uint64_t)b0 * ORDER_BUCKET_CAP + slot] = pos;
+                else
+                    *a.bucket_overflow = 1u;
+            }
+            todo &= ~same;
+        }
+    }
+}
 
 // One lane walks the window starts [lo, hi) of the tile at T (tile-local indices).
 // SKIP = false: the reference's loop as it stands (kernel1.cl:15-34), one window per
@@ -133,7 +214,7 @@ __device__ __forceinline__ void walk_lane(const ScanArgs &a, const LdsTables &tb
             while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
             if (k == m) { // kernel1.cl:24
                 const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-                emit_hit(a, astart - a.first, astart + a.out_bias);
+                report_hit(a, tb, astart, tile_off);
                 i += 1;
                 continue;
             }
@@ -165,7 +246,7 @@ __device__ __forceinline__ void walk_lane(const ScanArgs &a, const LdsTables &tb
                     while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
                     if (k == m) {
                         const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-                        emit_hit(a, astart - a.first, astart + a.out_bias);
+                        report_hit(a, tb, astart, tile_off);
                         i += 1;
                         continue;
                     }
@@ -217,7 +298,7 @@ __device__ __forceinline__ void walk_lane_qgram(const ScanArgs &a, const LdsTabl
         while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
         if (k == m) { // kernel1.cl:24
             const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-            emit_hit(a, astart - a.first, astart + a.out_bias);
+            report_hit(a, tb, astart, tile_off);
             i += 1;
             continue;
         }
@@ -247,7 +328,7 @@ __device__ __forceinline__ void walk_lane_b8(const ScanArgs &a, const LdsTables 
         while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
         if (k == m) {
             const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-            emit_hit(a, astart - a.first, astart + a.out_bias);
+            report_hit(a, tb, astart, tile_off);
             i += 1;
             continue;
         }
@@ -290,7 +371,7 @@ __device__ __forceinline__ void walk_lane_spec(const ScanArgs &a, const LdsTable
         while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
         if (k == m) { // kernel1.cl:24
             const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-            emit_hit(a, astart - a.first, astart + a.out_bias);
+            report_hit(a, tb, astart, tile_off);
             i += 1;
             continue;
         }
@@ -349,6 +430,7 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
         s_bad8[i] = (uint8_t)(v < 255 ? v : 255);
     }
     tb.bad8 = s_bad8;
+    uint8_t *end = s_bad8 + 256;
     tb.qtab = nullptr;
     if (QGRAM) { // every thread of the workgroup is here (two barriers)
         uint32_t *s_q = reinterpret_cast<uint32_t *>(s_bad8 + 256);
@@ -358,6 +440,18 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
             atomicMin(&s_q[qgram_hash(a.tab.pat[j - 3], a.tab.pat[j - 2], a.tab.pat[j - 1], a.tab.pat[j])], m - 1 - j);
         __syncthreads();
         tb.qtab = s_q;
+        end = reinterpret_cast<uint8_t *>(s_q + QGRAM_TABLE);
+    }
+    // parking areas for matches: [waves x stage_cap entries | waves counters]
+    tb.stage_cap = a.stage_cap;
+    tb.stage = nullptr;
+    tb.stage_cnt = nullptr;
+    if (a.stage_cap != 0) {
+        const uint32_t waves = nthreads >> 6, wave = tid >> 6;
+        lds_u32 *area = (lds_u32 *)to_lds(end);
+        tb.stage = area + wave * a.stage_cap;
+        tb.stage_cnt = area + waves * a.stage_cap + wave;
+        if ((tid & 63) == 0) *tb.stage_cnt = 0; // visible to the wave itself at once (LDS keeps a wave's order)
     }
     tb.m = m;
     tb.m4 = m >= 4;

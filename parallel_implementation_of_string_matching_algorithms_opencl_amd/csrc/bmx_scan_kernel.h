@@ -48,8 +48,11 @@ namespace bmx {
 // wave has started its walk (a wave's own DMA instructions must be accepted first),
 // and the waves released last make everybody wait at the barrier (~1500 cycles).
 // A dedicated loader wave takes both off the walkers' critical path.
+// amdgpu_num_sgpr(80): measured on MI355X, a kernel with more than 80 SGPRs gets 7, not 8, waves per SIMD
+// (the hardware adds a 16-SGPR reserve per wave to the 16-granule allocation), and the 36 KiB-tile variants then
+// lose their second workgroup per CU: 2.25 -> 1.6 TB/s on 4 GiB ACGT when the kernel grew from 80 to 85 SGPRs.
 template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0, int LOADERS = 0>
-__global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void scan_kernel(const ScanArgs a_in)
 {
     static_assert(SEG % 4 == 0 && (SEG / 4) % 2 == 1, "SEG must be 4 * odd (LDS bank spread)");
     static_assert(BLOCK % 64 == 0, "whole waves");
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a_in)
             else
                 walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
         }
+        if (MODE != 1) flush_stage(a, tb, tile_off); // the whole wave: the matches it parked while walking this tile
         if (MODE == 5) {
             const unsigned long long x = stamp();
             st_walk += x - st_prev;

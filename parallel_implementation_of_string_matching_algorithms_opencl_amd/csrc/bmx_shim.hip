@@ -161,14 +161,32 @@ uint64_t unit_bytes(const Variant &v)
     return v.kind != 1 ? (uint64_t)(v.block - 64 * v.loaders) * v.seg : 64ull * v.seg;
 }
 
-uint32_t lds_bytes_for(const Variant &v, int32_t m)
+// LDS of one workgroup with room for `cap` parked matches per wave (bmx_scan_common.h report_hit).
+uint32_t lds_bytes_with(const Variant &v, int32_t m, uint32_t cap)
 {
     const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
+    const uint32_t waves = (uint32_t)v.block / 64u;
     const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u) + 256 +
-                            (v.qgram ? bmx::QGRAM_TABLE * 4u : 0u);
+                            (v.qgram ? bmx::QGRAM_TABLE * 4u : 0u) + (cap ? waves * (cap + 1u) * 4u : 0u);
     if (v.kind != 1) return (uint32_t)v.nbuf * ((uint32_t)unit_bytes(v) + halo16) + tables;
-    return (uint32_t)(v.block / 64) * v.nbuf * (64u * v.seg + halo16) + tables;
+    return waves * v.nbuf * (64u * v.seg + halo16) + tables;
 }
+
+// Matches a wave may park in LDS per tile: workgroup-tile kernels only, and only as many as leave the
+// number of workgroups per CU alone (variant 2 lives on its second workgroup) and fit at all.
+uint32_t stage_cap_for(const Variant &v, int32_t m)
+{
+    if (v.kind != 0) return 0;
+    const uint32_t bare = lds_bytes_with(v, m, 0);
+    if (bare > LDS_PER_CU) return 0;
+    for (uint32_t cap = 128; cap >= 16; cap /= 2) {
+        const uint32_t with = lds_bytes_with(v, m, cap);
+        if (with <= LDS_PER_CU && LDS_PER_CU / with == LDS_PER_CU / bare) return cap;
+    }
+    return 0;
+}
+
+uint32_t lds_bytes_for(const Variant &v, int32_t m) { return lds_bytes_with(v, m, stage_cap_for(v, m)); }
 
 int blocks_per_cu_for(const bmx_ctx *ctx, const Variant &v, int32_t m)
 {
@@ -411,6 +429,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         a.bucket_overflow = ctx->d_overflow;
         a.bucket_shift = 0;
         a.stamps = nullptr;
+        a.stage_cap = stage_cap_for(v, m);
         while (((n_starts - 1) >> a.bucket_shift) >= (uint64_t)bmx::ORDER_BUCKETS) ++a.bucket_shift;
         a.m = (uint32_t)m;
         a.halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;

@@ -490,3 +490,20 @@ def test_cpp_driver_second_and_third_program(ctx, port, tmp_path):
     assert [int(x) for x in lines[1].split()] == port.suffix_array(np.frombuffer(txt, dtype=np.uint8)).tolist()
     r = subprocess.run([exe, "--edit-distance", "nope.txt", "str2.txt"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "File Not Found" in r.stderr
+
+
+def test_dense_results_short_patterns(ctx, port):
+    """m = 1 and 2 on text where one position in 20..100 matches: the walkers park their matches in
+    LDS per tile (report_hit / flush_stage); more than fit per wave and tile go the direct way."""
+    rng = np.random.default_rng(99)
+    try:
+        for v in (-1, 0, 2, 24):
+            ctx.set_variant(v)
+            for alpha, m, n in ((95, 1, 3_000_000), (20, 1, 700_000), (4, 1, 300_000), (1, 1, 70_000),
+                                (20, 2, 2_000_000), (4, 2, 500_000), (2, 3, 400_000), (3, 12, 900_000)):
+                text = (rng.integers(0, alpha, n) + 48).astype(np.uint8)
+                pat = text[n // 3:n // 3 + m].tobytes()
+                got = dev_search(ctx, text, pat)
+                assert np.array_equal(got, port.search(text, pat)), (v, alpha, m, n)
+    finally:
+        ctx.set_variant(0)
