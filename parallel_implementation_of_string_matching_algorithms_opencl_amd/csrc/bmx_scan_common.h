@@ -309,6 +309,47 @@ __device__ __forceinline__ void walk_lane_qgram(const ScanArgs &a, const LdsTabl
     }
 }
 
+// ---- m = 1..3: compare every position, four at a time ---------------------------------------
+// With m <= 3 the shift tables cannot skip anything worth the two dependent LDS reads per window
+// (printable text, m = 2: 34 rounds per 68-byte segment).  The same windows are tested here from
+// aligned dwords: byte j of `cur` starts a match iff it equals pat[0] and the bytes one and two
+// places on (v_alignbyte over the next dword) equal pat[1], pat[2] -- exact zero-byte masks, no
+// table.  The reference's loop visits exactly these windows when every shift is 1
+// (kernel1.cl:19-34 with d1 = d2 = 1), so the match list is the same.
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t v, uint32_t splat) // 0x80 in every byte of v equal to splat's
+{
+    const uint32_t x = v ^ splat;
+    return ~((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) | 0x7f7f7f7fu);
+}
+
+__device__ __forceinline__ void walk_lane_short(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
+                                                uint32_t hi, uint64_t tile_off)
+{
+    const uint32_t m = tb.m; // 1..3, wave-uniform
+    const uint32_t p0 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[0]) * 0x01010101u;
+    const uint32_t p1 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 1 ? 1 : 0]) * 0x01010101u;
+    const uint32_t p2 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 2 ? 2 : 0]) * 0x01010101u;
+    uint32_t d = lo & ~3u;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(T + d);
+    uint32_t cur = p[0];
+    for (; d < hi; d += 4) {
+        ++p;
+        const uint32_t nxt = p[0]; // up to 7 bytes past the last window: inside the workgroup's LDS, masked below
+        uint32_t e = eq_bytes(cur, p0);
+        if (m > 1) e &= eq_bytes(__builtin_amdgcn_alignbyte(nxt, cur, 1), p1);
+        if (m > 2) e &= eq_bytes(__builtin_amdgcn_alignbyte(nxt, cur, 2), p2);
+        // window starts d..d+3, of which [lo, hi) are this lane's
+        if (d < lo) e &= 0xffffffffu << (8u * (lo - d));
+        if (d + 4 > hi) e &= 0xffffffffu >> (8u * (d + 4 - hi));
+        while (e != 0) {
+            const uint32_t j = (uint32_t)(__ffs((int)e) - 1) >> 3;
+            report_hit(a, tb, tile_off + (uint64_t)(d + j), tile_off);
+            e &= e - 1;
+        }
+        cur = nxt;
+    }
+}
+
 // ---- byte-wise walker on the 8-bit copy of the bad-symbol table (m <= 255) ------------------
 __device__ __forceinline__ void walk_lane_b8(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
                                              uint32_t hi, uint64_t tile_off)

@@ -38,7 +38,8 @@ namespace bmx {
 // timing the two halves alone and return wrong match lists.
 // WALK 0: byte-wise walker, any m.  WALK 2: skip-loop walker, needs m >= 4.  WALK 3: 4-gram
 // walker (bmx_scan_common.h), needs m >= 4 and 16 KiB more LDS.  WALK 4: byte-wise walker with two
-// windows in flight.
+// windows in flight.  WALK 6: m = 1..3, every position compared from aligned dwords (the workgroup-tile
+// kernels' walker for short patterns).
 // (A WALK 1 that fetched the last four characters with one unaligned ds_read_b32 was
 // 35 % slower -- unaligned LDS dwords -- and is gone)
 // LOADERS: 0 = every wave issues its share of the tile DMA and then walks.
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void sc
                 walk_lane_spec(a, tb, T, lo, hi, tile_off);
             else if constexpr (WALK == 5)
                 walk_lane_b8(a, tb, T, lo, hi, tile_off);
+            else if constexpr (WALK == 6)
+                walk_lane_short(a, tb, T, lo, hi, tile_off);
             else
                 walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
         }

@@ -75,7 +75,7 @@ struct Variant {
 
 #define BMX_TILE(B, S, AUX, MODE, W) BMX_TILE_L(B, S, AUX, MODE, W, 0)
 #define BMX_TILE_L(B, S, AUX, MODE, W, L) \
-    {0, B, S, 2, L, (MODE) == 5, (W) == 3, bmx::scan_kernel<B, S, AUX, MODE, W, L>, bmx::scan_kernel<B, S, AUX, MODE, 0, L>}
+    {0, B, S, 2, L, (MODE) == 5, (W) == 3, bmx::scan_kernel<B, S, AUX, MODE, W, L>, bmx::scan_kernel<B, S, AUX, MODE, 6, L>}
 #define BMX_RING(B, S, AUX, SKIP, MODE) BMX_RING_P(B, S, AUX, SKIP, MODE, 0)
 #define BMX_RING_P(B, S, AUX, SKIP, MODE, P) \
     {2, B, S, 3, 0, (MODE) == 5, false, bmx::scan_ring_kernel<B, S, AUX, SKIP, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, false, MODE, P>}
