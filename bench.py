@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="searches in flight (each with its own context and output buffer); 1 = strictly one at a time")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N > 1 code path (RCCL process group, slot all-gather, merge) even with one rank: "
                          "a 1-GPU check of the calls the 2/4/8-GPU runs make")
@@ -237,40 +239,62 @@ def main():
     pat = spec.pattern()
     m = spec.m
 
-    ctx = host.Context(local_rank)
-    if args.variant >= 0:
-        ctx.set_variant(args.variant)
+    # Two searches in flight (--in-flight 2): each has its own context (device counters, pinned status
+    # word, event ring), output buffer and -- for N > 1 -- slot exchange; they alternate on ONE stream,
+    # so while the host waits for search k and launches search k+2, the GPU is already scanning for
+    # search k+1.  A step is still one complete search whose result the host collects (one step later).
     start, length, n_own = shard.shard_extent(spec.n, m, world, rank)
-    d_text = spec.device_text(ctx, start, length, device=dev)
     tables = host.build_tables(pat)  # host tables once, like BoyreMoore.cpp:150-190 (outside its timer too)
-
-    state = {}
-    if multi:
-        xchg = shard.SlotExchange(ctx, world, rank, dev, slot=SLOT, via_host=rehearse)  # [count | offsets...] over RCCL
-        out = xchg.out
-    else:
-        xchg = None
-        out = torch.zeros(SLOT, dtype=torch.int64, device=dev)
-    query = ctx.prepare(d_text, pat, out, n=length, n_own=n_own, base_offset=start, tables=tables)
-
-    def step():
+    lanes = []
+    for li in range(max(1, args.in_flight)):
+        c = host.Context(local_rank)
+        if args.variant >= 0:
+            c.set_variant(args.variant)
+        if li == 0:
+            d_text = spec.device_text(c, start, length, device=dev)
         if multi:
-            state["result"] = xchg.run(query)  # scan + order + all-gather + merge; one stream sync
+            x = shard.SlotExchange(c, world, rank, dev, slot=SLOT, via_host=rehearse)  # [count | offsets...] over RCCL
+            o = x.out
         else:
-            query.enqueue()
-            state["result"] = out[:query.finish()]  # the step's one host wait (polls the pinned status word)
+            x = None
+            o = torch.zeros(SLOT, dtype=torch.int64, device=dev)
+        q = c.prepare(d_text, pat, o, n=length, n_own=n_own, base_offset=start, tables=tables)
+        lanes.append({"ctx": c, "xchg": x, "out": o, "query": q, "pending": False, "result": None, "started": 0})
+    ctx = lanes[0]["ctx"]
+
+    def collect(lane):
+        if lane["pending"]:
+            if multi:
+                lane["result"] = lane["xchg"].finish(lane["query"])  # polls the pinned totals of the merge kernel
+            else:
+                lane["result"] = lane["out"][:lane["query"].finish()]  # polls the pinned status word
+            lane["pending"] = False
+
+    def step(i):
+        lane = lanes[i % len(lanes)]
+        collect(lane)  # the search this lane started len(lanes) steps ago
+        if multi:
+            lane["xchg"].start(lane["query"])  # scan + order + all-gather + merge
+        else:
+            lane["query"].enqueue()  # scan + order
+        lane["pending"] = True
+        lane["started"] += 1
 
     def fence():
+        for lane in lanes:
+            collect(lane)
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
+    for lane in lanes:
+        lane["started"] = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     fence()
     elapsed = time.perf_counter() - t0
     if multi:
@@ -279,16 +303,17 @@ def main():
         elapsed = float(t.item())
 
     # ---- correctness of what was timed --------------------------------------------------
-    result = state["result"].cpu().numpy().astype(np.uint64)
     want = spec.planted_offsets()
     if spec.pattern_from_text >= 0:
         want = np.unique(np.concatenate([want, np.array([spec.pattern_from_text], dtype=np.uint64)]))
-    planted_ok = bool(np.array_equal(result, want))
+    results = [lane["result"].cpu().numpy().astype(np.uint64) for lane in lanes if lane["result"] is not None]
+    result = results[0]
+    planted_ok = all(bool(np.array_equal(r, want)) for r in results)
 
     total_bytes = spec.n  # every rank's owned bytes, summed
     value = total_bytes * args.steps / elapsed / 1e9
     # HIP events recorded around every scan kernel of the timed region (ring of 64), read afterwards
-    scan_ms = ctx.scan_ms_history(min(args.steps, 64))
+    scan_ms = np.concatenate([lane["ctx"].scan_ms_history(min(lane["started"], 64)) for lane in lanes if lane["started"]])
     avg_scan_ms = float(np.mean(scan_ms))
     if multi:  # roofline of the slowest rank's kernel
         t = torch.tensor([avg_scan_ms], dtype=torch.float64, device=cdev)
@@ -304,7 +329,7 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": spec.name, "text_bytes_total": spec.n, "text_bytes_per_gpu": n_own,
                    "pattern_bytes": m, "alphabet": "printable-95" if spec.kind == 0 else "ACGT",
-                   "matches": int(result.size), "sharding": f"{world} contiguous shard(s) + {m - 1} B halo",
+                   "matches": int(result.size), "searches_in_flight": len(lanes), "sharding": f"{world} contiguous shard(s) + {m - 1} B halo",
                    "exchange": ("REHEARSAL on one GPU, gloo via host" if rehearse else
                                 "RCCL all-gather of [count|offsets] slots") if multi else "none",
                    "kernel": f"{geom['kind']} block {geom['block']} seg {geom['seg']} grid {geom['grid']} "
@@ -333,7 +358,8 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for lane in lanes:
+        lane["ctx"].close()
     if not ok:
         sys.exit(1)
 

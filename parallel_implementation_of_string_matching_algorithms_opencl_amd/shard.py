@@ -89,6 +89,13 @@ class SlotExchange:
 
     def run(self, query):
         """query: host.PreparedSearch bound to ``self.out``.  Returns the global list (device tensor)."""
+        self.start(query)
+        return self.finish(query)
+
+    def start(self, query):
+        """Enqueue scan, ordering, all-gather and merge; returns without waiting.  Another
+        SlotExchange (with its own Context) may be started before this one is finished: the
+        collectives are issued in the same order on every rank."""
         import torch
         import torch.distributed as dist
 
@@ -103,6 +110,11 @@ class SlotExchange:
             dist.all_gather_into_tensor(self.gathered, self.buf, group=self.group)
         self.seq += 1
         self.ctx.merge_gathered(self.gathered, self.world, self.slot + 1, self.merged, self.totals, self.seq)
+
+    def finish(self, query):
+        """Wait for what :meth:`start` enqueued; returns the global list (device tensor)."""
+        import torch
+
         local_total = query.finish()
         spins = 0
         while int(self.totals[2]) != self.seq:  # written last by the merge kernel (system-scope release)
