@@ -9,7 +9,7 @@ from parallel_implementation_of_string_matching_algorithms_opencl_amd import hos
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=300)
 ap.add_argument("--seed", type=int, default=12345)
-ap.add_argument("--variants", type=int, default=12)
+ap.add_argument("--variants", default="-1,0,1,2,3,4,5,6,7,8,9,10,11,20,21,22,23,24,25,26,27")  # -1: automatic choice
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 ctx = host.Context(0)
@@ -31,7 +31,7 @@ for case in range(args.cases):
     d = torch.from_numpy(text).cuda(int(0))
     off = int(rng.integers(0, 16)) if n > 32 else 0
     out = torch.empty(max(16, want.size + 8), dtype=torch.int64, device="cuda")
-    for v in range(args.variants):
+    for v in [int(x) for x in args.variants.split(',')]:
         ctx.set_variant(v)
         view = d[off:]
         pos, total = ctx.search_device(view, pat, out=out)
@@ -41,5 +41,5 @@ for case in range(args.cases):
             bad += 1
             print("MISMATCH", dict(case=case, variant=v, n=n, m=m, alpha=alpha, off=off, total=total, want=exp.size), flush=True)
     total_hits += want.size
-print(f"cases {args.cases} x variants {args.variants}: mismatches {bad}, hits checked {total_hits}, {time.time()-t0:.1f} s")
+print(f"cases {args.cases} x variants [{args.variants}]: mismatches {bad}, hits checked {total_hits}, {time.time()-t0:.1f} s")
 sys.exit(1 if bad else 0)
