@@ -77,8 +77,10 @@ __global__ void sa_copy_out(const uint32_t *idx_sorted, uint32_t n, int32_t *sa)
 } // namespace
 
 // d_sa[j] = start of the j-th suffix in the reference's order.  Returns BMX_OK / BMX_ERR_HIP.
+// *ws / *ws_bytes: the caller's workspace slot (the context keeps it between calls: eight hipMalloc +
+// hipFree per call cost 2 ms next to a 6 ms construction); grown here when too small.
 int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, hipStream_t stream, float *ms_out,
-                              int *rounds_out, char *err, size_t errlen)
+                              int *rounds_out, void **ws, size_t *ws_bytes, char *err, size_t errlen)
 {
     if (ms_out) *ms_out = -1.0f;
     if (rounds_out) *rounds_out = 0;
@@ -92,16 +94,31 @@ int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, 
     hipError_t e = hipSuccess;
     auto ok = [&]() { return e == hipSuccess; };
 
-    for (int b = 0; b < 2 && ok(); ++b) {
-        e = hipMalloc(&keys[b], (size_t)n * sizeof(uint64_t));
-        if (ok()) e = hipMalloc(&idx[b], (size_t)n * sizeof(uint32_t));
-    }
-    if (ok()) e = hipMalloc(&rank, (size_t)n * sizeof(uint32_t));
-    if (ok()) e = hipMalloc(&flags, (size_t)n * sizeof(uint32_t));
-    if (ok()) e = hipMalloc(&scanned, (size_t)n * sizeof(uint32_t));
-    if (ok()) e = rocprim::radix_sort_pairs(nullptr, tmp_sort, keys[0], keys[1], idx[0], idx[1], (size_t)n, 0, 64, stream);
+    // the size queries of rocPRIM only look at the types
+    e = rocprim::radix_sort_pairs(nullptr, tmp_sort, keys[0], keys[1], idx[0], idx[1], (size_t)n, 0, 64, stream);
     if (ok()) e = rocprim::inclusive_scan(nullptr, tmp_scan, flags, scanned, (size_t)n, rocprim::plus<uint32_t>(), stream);
-    if (ok()) e = hipMalloc(&tmp, tmp_sort > tmp_scan ? tmp_sort : tmp_scan);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_keys = up((size_t)n * sizeof(uint64_t)), b_u32 = up((size_t)n * sizeof(uint32_t));
+    const size_t b_tmp = up(tmp_sort > tmp_scan ? tmp_sort : tmp_scan);
+    const size_t need = 2 * b_keys + 5 * b_u32 + b_tmp;
+    if (ok() && *ws_bytes < need) {
+        if (*ws) (void)hipFree(*ws);
+        *ws = nullptr;
+        *ws_bytes = 0;
+        e = hipMalloc(ws, need);
+        if (ok()) *ws_bytes = need;
+    }
+    if (ok()) {
+        char *p = (char *)*ws;
+        keys[0] = (uint64_t *)p, p += b_keys;
+        keys[1] = (uint64_t *)p, p += b_keys;
+        idx[0] = (uint32_t *)p, p += b_u32;
+        idx[1] = (uint32_t *)p, p += b_u32;
+        rank = (uint32_t *)p, p += b_u32;
+        flags = (uint32_t *)p, p += b_u32;
+        scanned = (uint32_t *)p, p += b_u32;
+        tmp = p;
+    }
     if (ok()) e = hipEventCreate(&e0);
     if (ok()) e = hipEventCreate(&e1);
 
@@ -150,14 +167,6 @@ int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, 
 
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    for (int b = 0; b < 2; ++b) {
-        if (keys[b]) (void)hipFree(keys[b]);
-        if (idx[b]) (void)hipFree(idx[b]);
-    }
-    if (rank) (void)hipFree(rank);
-    if (flags) (void)hipFree(flags);
-    if (scanned) (void)hipFree(scanned);
-    if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) {
         if (err) snprintf(err, errlen, "suffix array of %u characters: %s", n, hipGetErrorString(e));
         return BMX_ERR_HIP;

@@ -33,7 +33,7 @@ static_assert(bmx::MAX_PATTERN == BMX_MAX_PATTERN, "header and kernel disagree")
 int bmx_internal_radix_sort(uint64_t *d_keys, uint64_t n, hipStream_t stream, char *err, size_t errlen);
 // bmx_sa.hip
 int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, hipStream_t stream, float *ms_out,
-                              int *rounds_out, char *err, size_t errlen);
+                              int *rounds_out, void **ws, size_t *ws_bytes, char *err, size_t errlen);
 
 namespace {
 
@@ -133,6 +133,8 @@ struct bmx_ctx {
     uint64_t ed_ws_bytes = 0;
     uint64_t ed_ws_shape[3] = {0, 0, 0}; // (la, lb, W) of the call that last used it: same layout, stale tags only
     float sa_last_ms = -1.0f;
+    void *sa_ws = nullptr; // suffix-array workspace, kept between calls while it is small
+    size_t sa_ws_bytes = 0;
     int sa_last_rounds = 0;
     int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
     unsigned long long *d_count = nullptr; // live match counter; re-armed by order_kernel
@@ -320,6 +322,7 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
     if (ctx->ed_ws) (void)hipFree(ctx->ed_ws);
+    if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (int i = 0; i < bmx_ctx::EV_RING; ++i) {
         if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
@@ -626,6 +629,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
         fresh = ctx->ed_ws_shape[0] != la || ctx->ed_ws_shape[1] != lb || ctx->ed_ws_shape[2] != W;
     } else {
         if (ctx->ed_ws) (void)hipFree(ctx->ed_ws);
+    if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
         ctx->ed_ws = nullptr;
         ctx->ed_ws_bytes = 0;
         if (hipMalloc(&ws, bytes) != hipSuccess) {
@@ -835,8 +839,15 @@ int bmx_suffix_array_device(bmx_ctx *ctx, const void *d_text, uint64_t n, int32_
 {
     if (!ctx || (n > 0 && (!d_text || !d_sa)) || n >= (1ull << 31)) return BMX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
-    return bmx_internal_suffix_array((const uint8_t *)d_text, (uint32_t)n, d_sa, (hipStream_t)stream_v, &ctx->sa_last_ms,
-                                     &ctx->sa_last_rounds, g_err, sizeof g_err);
+    const int rc = bmx_internal_suffix_array((const uint8_t *)d_text, (uint32_t)n, d_sa, (hipStream_t)stream_v,
+                                             &ctx->sa_last_ms, &ctx->sa_last_rounds, &ctx->sa_ws, &ctx->sa_ws_bytes, g_err,
+                                             sizeof g_err);
+    if (ctx->sa_ws_bytes > ED_BAND_WS_KEEP) { // a large one is not kept
+        (void)hipFree(ctx->sa_ws);
+        ctx->sa_ws = nullptr;
+        ctx->sa_ws_bytes = 0;
+    }
+    return rc;
 }
 
 int bmx_suffix_array(bmx_ctx *ctx_in, const char *text, uint64_t n, int32_t *sa_out)
