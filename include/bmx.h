@@ -135,11 +135,19 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
 int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t capacity,
                              uint64_t *n_matches, void *stream);
 
+/* 1 if the most recent bmx_search_device_finish on ctx had to SORT the list (dense or clustered
+ * matches: the ordering kernel that runs right behind the scan could not do it from its position
+ * buckets).  Whoever consumed d_match_positions on the stream BEFORE _finish -- the multi-GPU
+ * exchange below does -- has then seen the unordered list and must take it again. */
+int bmx_last_search_sorted(bmx_ctx *ctx);
+
 /* ---- multi-GPU exchange helpers (the collective itself is RCCL, outside) ------ */
 
 /* Copy the match count of the most recent enqueue on ctx to d_dst[0], on-stream
  * (no host round trip): lets a rank publish [count | offsets...] as one fixed-size
- * slot of an all-gather. */
+ * slot of an all-gather.  If the list is not ordered yet at that point (dense or
+ * clustered matches: _finish will sort it) the published count has bit 62 set, i.e.
+ * it is larger than any slot, and every rank falls back to the exact exchange. */
 int bmx_count_to_device(bmx_ctx *ctx, uint64_t *d_dst, void *stream);
 
 /* After an all-gather of `world` slots of `slot_stride` uint64 each, laid out

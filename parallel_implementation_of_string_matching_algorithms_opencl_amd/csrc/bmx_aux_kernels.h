@@ -96,6 +96,8 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
         const uint64_t needs_sort = (out != nullptr && !ordered && total > 1) ? 1 : 0; // host sorts the unordered list
         status[0] = total;
         status[1] = needs_sort;
+        // what bmx_count_to_device publishes: a list that is not ordered yet counts as larger than any slot
+        status[2] = needs_sort ? (total | (1ull << 62)) : total;
         *count = 0;
         *bucket_overflow = 0;
         // the host polls host_status[2] (pinned, fine-grained) for this search's sequence number

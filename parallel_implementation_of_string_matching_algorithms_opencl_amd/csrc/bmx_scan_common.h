@@ -48,7 +48,7 @@ struct ScanArgs {
     unsigned long long *stamps; // MODE 5 only (diagnostic build): per-wave cycle sums, 8 words per wave
     uint32_t m;
     uint32_t halo16;         // (m-1) rounded up to a multiple of 16
-    uint32_t stage_cap;      // matches a wave can park in LDS per tile before it appends to HBM (0: none)
+    uint32_t stage_cap;      // matches a workgroup can park in LDS per tile before they are appended to HBM (0: none)
     ScanTables tab;
 };
 
@@ -104,9 +104,10 @@ struct LdsTables {
     const uint8_t *pat;   // m bytes
     const uint32_t *qtab; // QGRAM_TABLE x u32, 4-gram walker only
     const uint8_t *bad8;  // 256 x u8 copy of bad[] (m <= 255): 64 LDS words = 2 per bank instead of 4
-    lds_u32 *stage;       // this wave's parking area for matches: tile-local window starts
+    lds_u32 *stage;       // the workgroup's parking buffer for the tile being walked: tile-local window starts
     lds_u32 *stage_cnt;   // how many it holds (may run past stage_cap: the excess went straight to HBM)
-    uint32_t stage_cap;
+    lds_u32 *stage_area;  // [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
+    uint32_t stage_cap;   // entries per buffer
     uint32_t m;
     // scalar copies for the skip-loop walker
     uint32_t b_last, p3, g1, g2, g3;
@@ -116,8 +117,12 @@ struct LdsTables {
 // A match found by a walker (called under divergence).  Appending to HBM costs a global atomic with
 // its round trip INSIDE the walk loop (and hipcc drains the LDS-DMA in flight with it): fine for one
 // match per MiB, a cliff for dense results (1 GiB printable text, m = 1: 12.6 M matches took 107 ms).
-// So a wave parks its matches of the current tile in LDS (one LDS atomic per call) and appends them
-// together once it has walked the tile (flush_stage); what does not fit goes the direct way.
+// So the workgroup parks the matches of the tile it is walking in LDS -- one LDS atomic per call, issued
+// as inline asm: around a builtin LDS atomic hipcc drains vmcnt, i.e. waits for the tile DMA in flight --
+// and appends them together, with ONE global atomic, while it walks the next tile (scan_kernel).  One
+// reservation per workgroup and tile matters: every append increments the same counter and the chip
+// retires ~80 M same-address atomics per second, so per wave and tile (first version) 246 k flushes for
+// the 12.6 M matches above still took 3.0 ms.  What does not fit in the buffer goes the direct way.
 __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &tb, uint64_t astart, uint64_t tile_off)
 {
     if (tb.stage_cap != 0) { // wave-uniform
@@ -125,14 +130,10 @@ __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &t
         const uint32_t lane = __lane_id();
         const int leader = __ffsll((unsigned long long)active) - 1;
         const uint32_t rank = __popcll(active & ((1ull << lane) - 1ull));
-        // the counter is this wave's alone and the wave runs this sequence one divergent branch at a time:
-        // a plain read-modify-write by the leader, through volatile so that no lane keeps a stale copy in a
-        // register (an LDS ATOMIC here makes hipcc drain vmcnt first, i.e. wait for the tile DMA in flight)
-        lds_u32 *cnt = tb.stage_cnt;
         uint32_t base = 0;
         if ((int)lane == leader) {
-            base = *cnt;
-            *cnt = base + (uint32_t)__popcll(active);
+            const uint32_t addr = (uint32_t)(uintptr_t)tb.stage_cnt, n = (uint32_t)__popcll(active);
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(addr), "v"(n) : "memory");
         }
         base = __shfl(base, leader);
         if (base + rank < tb.stage_cap) {
@@ -143,48 +144,47 @@ __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &t
     emit_hit(a, astart - a.first, astart + a.out_bias);
 }
 
-// The whole wave, after its walk of a tile: append the parked matches (one global atomic per 64) and
-// enter them into their position buckets (one atomic per distinct bucket among 64 matches).
-__device__ __forceinline__ void flush_stage(const ScanArgs &a, const LdsTables &tb, uint64_t tile_off)
+// Second half of an append (all threads of the workgroup, `n` > 0 matches of the tile at `tile_off`
+// parked in `buf`): thread 0 publishes the base its global atomic returned -- issued before this tile's
+// DMA, consumed here, after the walk, when the wait for it costs nothing that the loop's own wait for
+// the DMA would not cost anyway -- everybody else waits for it on an LDS flag, then the workgroup
+// stores the offsets.  Position buckets (the sort-free ordering of sparse results) are fed by a tile with
+// up to 16 matches; with more the workgroup declares them overflowed (results that dense outgrow them
+// anyway) and the list is ordered by a sort.
+template <uint32_t BLOCK>
+__device__ __forceinline__ void finish_parked(const ScanArgs &a, const LdsTables &tb, uint64_t tile_off, lds_u32 *buf,
+                                              lds_u32 *cnt, uint32_t n, unsigned long long reserved, uint32_t ticket)
 {
-    if (tb.stage_cap == 0) return;
-    const uint32_t lane = __lane_id();
-    lds_u32 *cnt_p = tb.stage_cnt;
-    uint32_t n = __builtin_amdgcn_readfirstlane(*cnt_p);
-    if (n == 0) return;
-    if (lane == 0) *cnt_p = 0;
-    n = n < tb.stage_cap ? n : tb.stage_cap;
-    // once a bucket has overflowed the list is ordered by a sort anyway: stop feeding the buckets
-    const bool buckets = a.out != nullptr && __builtin_amdgcn_readfirstlane(*a.bucket_overflow) == 0;
-    for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const bool valid = j < n;
-        const uint64_t astart = tile_off + (valid ? tb.stage[j] : 0u);
+    lds_u32 *flag = tb.stage_area + 2 * tb.stage_cap + 2, *base_w = tb.stage_area + 2 * tb.stage_cap + 4;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        base_w[0] = (uint32_t)reserved;
+        base_w[1] = (uint32_t)(reserved >> 32);
+        *cnt = 0; // every wave read it after the barrier; the next parking into this buffer is two barriers away
+        *flag = ticket; // LDS keeps a wave's stores in order: the base is there when the ticket is
+    }
+    uint32_t spins = 0;
+    while (*flag != ticket) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 24)) __builtin_trap(); // thread 0 always gets here: a bound, not a path
+    }
+    if (a.out == nullptr) return;
+    const unsigned long long base = ((unsigned long long)base_w[1] << 32) | base_w[0];
+    // a position bucket is at least as long as a tile (texts of 0.5 GiB and more) and holds 8: a tile with
+    // more than 16 matches overflows its one or two buckets for certain
+    const bool buckets = n <= 2u * ORDER_BUCKET_CAP;
+    if (!buckets && tid == 0) *a.bucket_overflow = 1u;
+    for (uint32_t j = tid; j < n; j += BLOCK) {
+        const uint64_t astart = tile_off + buf[j];
         const uint64_t pos = astart + a.out_bias;
-        const uint32_t cnt = n - j0 < 64 ? n - j0 : 64;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(a.count, (unsigned long long)cnt);
-        base = __shfl(base, 0);
-        if (a.out == nullptr) continue;
-        if (valid && base + lane < a.cap) a.out[base + lane] = pos;
-        if (!buckets) continue;
-        const uint32_t b = (uint32_t)((astart - a.first) >> a.bucket_shift);
-        uint64_t todo = __ballot(valid);
-        while (todo != 0) { // wave-uniform: one round per distinct bucket
-            const int l0 = __ffsll((unsigned long long)todo) - 1;
-            const uint32_t b0 = __shfl(b, l0);
-            const uint64_t same = __ballot(valid && b == b0) & todo;
-            uint32_t s0 = 0;
-            if ((int)lane == l0) s0 = atomicAdd(&a.bucket_cnt[b0], (uint32_t)__popcll(same));
-            s0 = __shfl(s0, l0);
-            if ((same >> lane) & 1ull) {
-                const uint32_t slot = s0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                if (slot < (uint32_t)ORDER_BUCKET_CAP)
-                    a.bucket_store[(uint64_t)b0 * ORDER_BUCKET_CAP + slot] = pos;
-                else
-                    *a.bucket_overflow = 1u;
-            }
-            todo &= ~same;
+        if (base + j < a.cap) a.out[base + j] = pos;
+        if (buckets) {
+            const uint32_t b = (uint32_t)((astart - a.first) >> a.bucket_shift);
+            const uint32_t slot = atomicAdd(&a.bucket_cnt[b], 1u);
+            if (slot < (uint32_t)ORDER_BUCKET_CAP)
+                a.bucket_store[(uint64_t)b * ORDER_BUCKET_CAP + slot] = pos;
+            else
+                *a.bucket_overflow = 1u;
         }
     }
 }
@@ -483,16 +483,16 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
         tb.qtab = s_q;
         end = reinterpret_cast<uint8_t *>(s_q + QGRAM_TABLE);
     }
-    // parking areas for matches: [waves x stage_cap entries | waves counters]
+    // parking area for matches: [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
     tb.stage_cap = a.stage_cap;
-    tb.stage = nullptr;
-    tb.stage_cnt = nullptr;
+    tb.stage = tb.stage_cnt = tb.stage_area = nullptr;
     if (a.stage_cap != 0) {
-        const uint32_t waves = nthreads >> 6, wave = tid >> 6;
         lds_u32 *area = (lds_u32 *)to_lds(end);
-        tb.stage = area + wave * a.stage_cap;
-        tb.stage_cnt = area + waves * a.stage_cap + wave;
-        if ((tid & 63) == 0) *tb.stage_cnt = 0; // visible to the wave itself at once (LDS keeps a wave's order)
+        tb.stage_area = area;
+        tb.stage = area;
+        tb.stage_cnt = area + 2 * a.stage_cap;
+        if (tid < 2) area[2 * a.stage_cap + tid] = 0;        // the counters
+        if (tid == 2) area[2 * a.stage_cap + 2] = 0xFFFFFFFFu; // no ticket yet
     }
     tb.m = m;
     tb.m4 = m >= 4;

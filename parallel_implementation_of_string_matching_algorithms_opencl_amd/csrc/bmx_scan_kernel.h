@@ -49,11 +49,8 @@ namespace bmx {
 // wave has started its walk (a wave's own DMA instructions must be accepted first),
 // and the waves released last make everybody wait at the barrier (~1500 cycles).
 // A dedicated loader wave takes both off the walkers' critical path.
-// amdgpu_num_sgpr(80): measured on MI355X, a kernel with more than 80 SGPRs gets 7, not 8, waves per SIMD
-// (the hardware adds a 16-SGPR reserve per wave to the 16-granule allocation), and the 36 KiB-tile variants then
-// lose their second workgroup per CU: 2.25 -> 1.6 TB/s on 4 GiB ACGT when the kernel grew from 80 to 85 SGPRs.
 template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0, int LOADERS = 0>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void scan_kernel(const ScanArgs a_in)
+__device__ __forceinline__ void scan_body(const ScanArgs &a)
 {
     static_assert(SEG % 4 == 0 && (SEG / 4) % 2 == 1, "SEG must be 4 * odd (LDS bank spread)");
     static_assert(BLOCK % 64 == 0, "whole waves");
@@ -62,7 +59,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void sc
     constexpr uint32_t TILE = WALKERS * SEG;
     static_assert(TILE % 16 == 0, "tiles start on 16-B chunks");
 
-    const ScanArgs &a = a_in;
     extern __shared__ uint4 smem_u4[];
     uint8_t *smem = reinterpret_cast<uint8_t *>(smem_u4);
     const uint32_t buf_bytes = TILE + a.halo16; // multiple of 16
@@ -71,7 +67,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void sc
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lane = tid & 63;
-    const LdsTables tb = load_tables<WALK == 2, WALK == 3>(a, smem + 2 * buf_bytes, tid, BLOCK);
+    LdsTables tb = load_tables<WALK == 2, WALK == 3>(a, smem + 2 * buf_bytes, tid, BLOCK);
 
     const uint32_t nchunk = buf_bytes >> 4; // 16-B chunks per tile incl. halo
     auto issue_tile = [&](uint64_t t, uint8_t *dst) {
@@ -90,6 +86,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void sc
     const bool issues = LOADERS == 0 || is_loader;
     const uint32_t wtid = tid - 64 * LOADERS; // walker lane index (meaningless for loaders)
     uint64_t t = a.tile_begin + blockIdx.x;
+    uint32_t it = 0; // tiles walked so far by this workgroup
+    auto park_buf = [&](uint32_t p) { return tb.stage_area + p * tb.stage_cap; };
+    auto park_cnt = [&](uint32_t p) { return tb.stage_area + 2 * tb.stage_cap + p; };
     if (t < a.tile_end && issues) issue_tile(t, buf0);
     uint32_t cur = 0;
     // MODE 5: where does a tile period go?  s_memtime stamps, summed per wave (the
@@ -115,6 +114,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void sc
             st_prev = x;
         }
         __syncthreads();
+        // Matches parked while the PREVIOUS tile was walked: reserve their slots now (one global atomic by
+        // one thread, not waited for), park this tile's matches in the other buffer meanwhile.
+        uint32_t prev_n = 0;
+        unsigned long long reserved = 0;
+        if (MODE != 1 && tb.stage_cap != 0) {
+            if (it != 0) {
+                prev_n = __builtin_amdgcn_readfirstlane(*park_cnt((it & 1u) ^ 1u));
+                prev_n = prev_n < tb.stage_cap ? prev_n : tb.stage_cap;
+                if (prev_n != 0 && tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
+            }
+            tb.stage = park_buf(it & 1u);
+            tb.stage_cnt = park_cnt(it & 1u);
+        }
         if (MODE == 5) {
             const unsigned long long x = stamp();
             st_bar += x - st_prev;
@@ -155,7 +167,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void sc
             else
                 walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
         }
-        if (MODE != 1) flush_stage(a, tb, tile_off); // the whole wave: the matches it parked while walking this tile
+        if (prev_n != 0) // the previous tile's matches: reserved before this tile's DMA, stored now
+            finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), park_cnt((it & 1u) ^ 1u),
+                                 prev_n, reserved, it);
+        ++it;
         if (MODE == 5) {
             const unsigned long long x = stamp();
             st_walk += x - st_prev;
@@ -163,6 +178,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void sc
             ++st_n;
         }
         cur ^= 1;
+    }
+    if (MODE != 1 && tb.stage_cap != 0 && it != 0) { // what the last tile left parked
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        uint32_t prev_n = __builtin_amdgcn_readfirstlane(*park_cnt((it & 1u) ^ 1u));
+        prev_n = prev_n < tb.stage_cap ? prev_n : tb.stage_cap;
+        if (prev_n != 0) {
+            unsigned long long reserved = 0;
+            if (tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
+            finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), park_cnt((it & 1u) ^ 1u),
+                                 prev_n, reserved, it);
+        }
     }
     if (MODE == 5 && a.stamps != nullptr && lane == 0) {
         unsigned long long *o = a.stamps + ((uint64_t)blockIdx.x * (BLOCK / 64) + wave) * 8;
@@ -172,6 +199,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void sc
         o[3] = st_bar;
         o[4] = st_n;
     }
+}
+
+template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0, int LOADERS = 0>
+__global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a)
+{
+    scan_body<BLOCK, SEG, AUX, MODE, WALK, LOADERS>(a);
+}
+
+// The same kernel for geometries that put 32 waves on a CU (two workgroups of 16): measured on MI355X, a
+// kernel with more than 80 SGPRs gets 7, not 8, waves per SIMD (a 16-SGPR reserve per wave on top of the
+// 16-granule allocation; hipcc still reports occupancy 8), and the second workgroup does not fit: 2.25 ->
+// 1.6 TB/s on 4 GiB ACGT when the kernel grew from 80 to 85 SGPRs.  Pinned to 80 here (the others would
+// pay for the spills and have no use for the eighth wave).
+template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0, int LOADERS = 0>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void scan_kernel_w32(const ScanArgs a)
+{
+    scan_body<BLOCK, SEG, AUX, MODE, WALK, LOADERS>(a);
 }
 
 } // namespace bmx

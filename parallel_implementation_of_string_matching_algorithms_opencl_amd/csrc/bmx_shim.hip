@@ -76,6 +76,8 @@ struct Variant {
 #define BMX_TILE(B, S, AUX, MODE, W) BMX_TILE_L(B, S, AUX, MODE, W, 0)
 #define BMX_TILE_L(B, S, AUX, MODE, W, L) \
     {0, B, S, 2, L, (MODE) == 5, (W) == 3, bmx::scan_kernel<B, S, AUX, MODE, W, L>, bmx::scan_kernel<B, S, AUX, MODE, 6, L>}
+#define BMX_TILE_W32(B, S, AUX, MODE, W) /* 32 waves per CU: the 80-SGPR build */ \
+    {0, B, S, 2, 0, (MODE) == 5, (W) == 3, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, MODE, 6, 0>}
 #define BMX_RING(B, S, AUX, SKIP, MODE) BMX_RING_P(B, S, AUX, SKIP, MODE, 0)
 #define BMX_RING_P(B, S, AUX, SKIP, MODE, P) \
     {2, B, S, 3, 0, (MODE) == 5, false, bmx::scan_ring_kernel<B, S, AUX, SKIP, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, false, MODE, P>}
@@ -85,7 +87,7 @@ const Variant g_variants[] = {
     // ---- products (every one parity-tested by tests/test_gpu_parity.py) ----
     BMX_TILE(1024, 68, 2, 0, 0),        // 0: default -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
     BMX_TILE(1024, 68, 2, 0, 2),        // 1: same tile, skip-loop walker
-    BMX_TILE(1024, 36, 2, 0, 2),        // 2: skip-loop walker, 36 KiB tiles, TWO workgroups = 32 waves per CU
+    BMX_TILE_W32(1024, 36, 2, 0, 2),    // 2: skip-loop walker, 36 KiB tiles, TWO workgroups = 32 waves per CU
                                         //    (picked automatically for small alphabets)
     BMX_TILE(768, 100, 2, 0, 0),        // 3
     BMX_TILE(256, 132, 2, 0, 0),        // 4: two workgroups per CU
@@ -109,7 +111,7 @@ const Variant g_variants[] = {
     BMX_TILE(512, 68, 2, 0, 0),         // 20: two workgroups of 8 waves per CU, 34 KiB tiles
     BMX_TILE(512, 76, 2, 0, 0),         // 21: same, 38 KiB tiles
     BMX_TILE(512, 132, 2, 0, 0),        // 22: one workgroup of 8 waves, 66 KiB tiles
-    BMX_TILE(1024, 36, 2, 0, 0),        // 23: variant 2's geometry with the byte-wise walker
+    BMX_TILE_W32(1024, 36, 2, 0, 0),    // 23: variant 2's geometry with the byte-wise walker
     BMX_TILE(1024, 68, 2, 0, 3),        // 24: default geometry, 4-gram walker (picked automatically for small alphabets)
     BMX_TILE(1024, 36, 2, 0, 3),        // 25: 4-gram walker, 36 KiB tiles, two workgroups per CU
     BMX_TILE(1024, 68, 2, 0, 4),        // 26: default geometry, byte-wise walker with two windows in flight
@@ -148,6 +150,7 @@ struct bmx_ctx {
     unsigned long long *d_stamps = nullptr; // diagnostic builds only (bmx_scan_stamps)
     uint64_t stamp_words = 0;
     bool armed = false;                    // counters known to be zero
+    bool last_sorted = false;              // the last finish had to sort (the order kernel could not order the list)
     static constexpr int EV_RING = 64;     // event pairs around the last EV_RING scan kernels
     hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
     uint64_t n_timed = 0;                  // scan kernels launched with events so far
@@ -163,25 +166,25 @@ uint64_t unit_bytes(const Variant &v)
     return v.kind != 1 ? (uint64_t)(v.block - 64 * v.loaders) * v.seg : 64ull * v.seg;
 }
 
-// LDS of one workgroup with room for `cap` parked matches per wave (bmx_scan_common.h report_hit).
+// LDS of one workgroup with two buffers of `cap` parked matches (bmx_scan_common.h report_hit).
 uint32_t lds_bytes_with(const Variant &v, int32_t m, uint32_t cap)
 {
     const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
     const uint32_t waves = (uint32_t)v.block / 64u;
     const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u) + 256 +
-                            (v.qgram ? bmx::QGRAM_TABLE * 4u : 0u) + (cap ? waves * (cap + 1u) * 4u : 0u);
+                            (v.qgram ? bmx::QGRAM_TABLE * 4u : 0u) + (cap ? 2u * cap * 4u + 32u : 0u);
     if (v.kind != 1) return (uint32_t)v.nbuf * ((uint32_t)unit_bytes(v) + halo16) + tables;
     return waves * v.nbuf * (64u * v.seg + halo16) + tables;
 }
 
-// Matches a wave may park in LDS per tile: workgroup-tile kernels only, and only as many as leave the
+// Matches a workgroup may park in LDS per tile: workgroup-tile kernels only, and only as many as leave the
 // number of workgroups per CU alone (variant 2 lives on its second workgroup) and fit at all.
 uint32_t stage_cap_for(const Variant &v, int32_t m)
 {
     if (v.kind != 0) return 0;
     const uint32_t bare = lds_bytes_with(v, m, 0);
     if (bare > LDS_PER_CU) return 0;
-    for (uint32_t cap = 128; cap >= 16; cap /= 2) {
+    for (uint32_t cap = 2048; cap >= 128; cap /= 2) {
         const uint32_t with = lds_bytes_with(v, m, cap);
         if (with <= LDS_PER_CU && LDS_PER_CU / with == LDS_PER_CU / bare) return cap;
     }
@@ -292,7 +295,7 @@ int bmx_ctx_create(int device, bmx_ctx **out)
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_bucket_store, (size_t)bmx::ORDER_BUCKETS * bmx::ORDER_BUCKET_CAP * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_status, 2 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_status, 4 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 4 * sizeof(uint64_t), hipHostMallocMapped);
     if (e == hipSuccess) {
         std::memset(ctx->h_status, 0, 4 * sizeof(uint64_t));
@@ -359,6 +362,8 @@ int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6])
     out[5] = v.kind;
     return BMX_OK;
 }
+
+int bmx_last_search_sorted(bmx_ctx *ctx) { return ctx && ctx->last_sorted ? 1 : 0; }
 
 float bmx_last_scan_ms(bmx_ctx *ctx)
 {
@@ -513,6 +518,7 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
     }
     const uint64_t total = ctx->h_status[0];
     const bool needs_sort = ctx->h_status[1] != 0;
+    ctx->last_sorted = needs_sort;
     if (n_matches) *n_matches = total;
     const uint64_t stored = std::min(total, capacity);
     if (needs_sort && stored > 1 && d_match_positions) {
@@ -544,7 +550,7 @@ int bmx_count_to_device(bmx_ctx *ctx, uint64_t *d_dst, void *stream_v)
 {
     if (!ctx || !d_dst) return BMX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemcpyAsync(d_dst, ctx->d_status, sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream_v));
+    HIPCHK(hipMemcpyAsync(d_dst, ctx->d_status + 2, sizeof(uint64_t), hipMemcpyDeviceToDevice, (hipStream_t)stream_v));
     return BMX_OK;
 }
 

@@ -56,6 +56,7 @@ SYMBOLS = [
     ("bmx_search_device_enqueue", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p,
                                             C.c_int32, _i32p, _i32p, C.c_void_p, C.c_uint64, C.c_void_p]),
     ("bmx_search_device_finish", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, _u64p, C.c_void_p]),
+    ("bmx_last_search_sorted", C.c_int, [C.c_void_p]),
     ("bmx_count_to_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bmx_merge_gathered_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_uint64,
                                             C.c_void_p, C.c_uint64, C.c_void_p]),
@@ -305,6 +306,10 @@ class Context:
         _check(lib().bmx_scan_geometry(self._h, m, g), "bmx_scan_geometry")
         return {"grid": int(g[0]), "block": int(g[1]), "tile_bytes": int(g[2]), "lds_bytes": int(g[3]),
                 "seg": int(g[4]), "kind": ("workgroup-tile", "wave-stream", "workgroup-ring")[int(g[5])]}
+
+    def last_search_sorted(self) -> bool:
+        """Did the last finish() have to sort (the list was unordered until then)?"""
+        return bool(lib().bmx_last_search_sorted(self._h))
 
     def set_variant(self, variant: int, blocks_per_cu: int = 0):
         _check(lib().bmx_set_variant(self._h, variant, blocks_per_cu), "bmx_set_variant")

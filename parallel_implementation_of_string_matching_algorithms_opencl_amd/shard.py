@@ -122,7 +122,9 @@ class SlotExchange:
             if spins > 50_000_000:
                 raise RuntimeError("SlotExchange: merge kernel never published its totals")
         total, largest = int(self.totals[0]), int(self.totals[1])
-        if largest > self.slot:  # dense result somewhere: exact exchange (every rank takes this branch)
+        # dense result somewhere: exact exchange (every rank takes this branch).  A rank whose list is only
+        # ordered by finish() (a sort) has published a count with bit 62 set, so this covers it too.
+        if largest > self.slot:
             full = torch.empty(max(local_total, 1), dtype=torch.int64, device=self.buf.device)
             exact = self.ctx.prepare(query.d_text, query._pat, full, n=query.n, n_own=query.n_own,
                                      base_offset=query.base_offset, tables=query.tables)

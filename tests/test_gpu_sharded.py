@@ -180,3 +180,51 @@ def test_bench_distributed_path_on_rccl_with_one_rank(ctx):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["exchange"].startswith("RCCL")
     assert line["parity"]["planted_offsets_exact"] is True and line["config"]["matches"] > 100
+
+
+def _worker_cluster(port_no, q):
+    """One RCCL rank whose matches are clustered in one tile: the ordering kernel cannot order them from
+    its position buckets, finish() sorts -- after the slot was published.  The published count must
+    send the exchange down its exact path."""
+    import torch
+    import torch.distributed as dist
+
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import host, shard
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port_no)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(31)
+        text = (rng.integers(0, 95, 3 << 20) + 32).astype(np.uint8)
+        pat = b"clustered-needle"
+        starts = [70000 + 16 * i for i in range(40)] + [5, 1 << 20, (3 << 20) - 16]
+        for s in starts:
+            text[s:s + 16] = np.frombuffer(pat, dtype=np.uint8)
+        ctx = host.Context(0)
+        d_text = torch.from_numpy(text).to(dev)
+        xchg = shard.SlotExchange(ctx, 1, 0, dev, slot=8192)
+        query = ctx.prepare(d_text, pat, xchg.out, tables=host.build_tables(pat))
+        for _ in range(2):
+            res = xchg.run(query)
+        q.put((res.cpu().numpy().astype(np.uint64), np.array(sorted(starts), dtype=np.uint64), ctx.last_search_sorted()))
+        dist.barrier()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slot_exchange_when_the_list_is_only_ordered_by_finish(ctx):
+    import torch.multiprocessing as mp
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    p = mpc.Process(target=_worker_cluster, args=(_free_port(), q))
+    p.start()
+    got, want, sorted_by_finish = q.get(timeout=300)
+    p.join(timeout=300)
+    assert p.exitcode == 0
+    assert sorted_by_finish  # the case this test is about
+    assert np.array_equal(got, want)
