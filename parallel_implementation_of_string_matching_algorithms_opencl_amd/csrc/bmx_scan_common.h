@@ -105,7 +105,8 @@ struct LdsTables {
     const uint32_t *qtab; // QGRAM_TABLE x u32, 4-gram walker only
     const uint8_t *bad8;  // 256 x u8 copy of bad[] (m <= 255): 64 LDS words = 2 per bank instead of 4
     lds_u32 *stage;       // the workgroup's parking buffer for the tile being walked: tile-local window starts
-    lds_u32 *stage_cnt;   // how many it holds (may run past stage_cap: the excess went straight to HBM)
+    lds_u32 *stage_cnt;   // running count of matches sent to this buffer (never reset: stage_seen is subtracted)
+    uint32_t stage_seen;  // its value when this tile's walk began
     lds_u32 *stage_area;  // [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
     uint32_t stage_cap;   // entries per buffer
     uint32_t m;
@@ -135,7 +136,7 @@ __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &t
             const uint32_t addr = (uint32_t)(uintptr_t)tb.stage_cnt, n = (uint32_t)__popcll(active);
             asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(addr), "v"(n) : "memory");
         }
-        base = __shfl(base, leader);
+        base = __shfl(base, leader) - tb.stage_seen; // matches parked for this tile before mine
         if (base + rank < tb.stage_cap) {
             tb.stage[base + rank] = (uint32_t)(astart - tile_off);
             return;
@@ -153,14 +154,13 @@ __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &t
 // anyway) and the list is ordered by a sort.
 template <uint32_t BLOCK>
 __device__ __forceinline__ void finish_parked(const ScanArgs &a, const LdsTables &tb, uint64_t tile_off, lds_u32 *buf,
-                                              lds_u32 *cnt, uint32_t n, unsigned long long reserved, uint32_t ticket)
+                                              uint32_t n, unsigned long long reserved, uint32_t ticket)
 {
     lds_u32 *flag = tb.stage_area + 2 * tb.stage_cap + 2, *base_w = tb.stage_area + 2 * tb.stage_cap + 4;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) {
         base_w[0] = (uint32_t)reserved;
         base_w[1] = (uint32_t)(reserved >> 32);
-        *cnt = 0; // every wave read it after the barrier; the next parking into this buffer is two barriers away
         *flag = ticket; // LDS keeps a wave's stores in order: the base is there when the ticket is
     }
     uint32_t spins = 0;
@@ -486,6 +486,7 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
     // parking area for matches: [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
     tb.stage_cap = a.stage_cap;
     tb.stage = tb.stage_cnt = tb.stage_area = nullptr;
+    tb.stage_seen = 0;
     if (a.stage_cap != 0) {
         lds_u32 *area = (lds_u32 *)to_lds(end);
         tb.stage_area = area;

@@ -87,6 +87,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     const uint32_t wtid = tid - 64 * LOADERS; // walker lane index (meaningless for loaders)
     uint64_t t = a.tile_begin + blockIdx.x;
     uint32_t it = 0; // tiles walked so far by this workgroup
+    uint32_t seen[2] = {0, 0}; // the parking buffers' counts as of their last collection
     auto park_buf = [&](uint32_t p) { return tb.stage_area + p * tb.stage_cap; };
     auto park_cnt = [&](uint32_t p) { return tb.stage_area + 2 * tb.stage_cap + p; };
     if (t < a.tile_end && issues) issue_tile(t, buf0);
@@ -119,13 +120,20 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         uint32_t prev_n = 0;
         unsigned long long reserved = 0;
         if (MODE != 1 && tb.stage_cap != 0) {
+            // The counters only ever grow (nobody resets them, so nobody can reset them too early): what a
+            // buffer received for its last tile is its count now minus its count when that walk began.  Every
+            // wave reads the same count here -- the next match goes to this buffer two barriers from now.
+            const uint32_t pp = (it & 1u) ^ 1u;
             if (it != 0) {
-                prev_n = __builtin_amdgcn_readfirstlane(*park_cnt((it & 1u) ^ 1u));
+                const uint32_t now = __builtin_amdgcn_readfirstlane(*park_cnt(pp));
+                prev_n = now - seen[pp];
+                seen[pp] = now;
                 prev_n = prev_n < tb.stage_cap ? prev_n : tb.stage_cap;
                 if (prev_n != 0 && tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
             }
             tb.stage = park_buf(it & 1u);
             tb.stage_cnt = park_cnt(it & 1u);
+            tb.stage_seen = seen[it & 1u];
         }
         if (MODE == 5) {
             const unsigned long long x = stamp();
@@ -168,8 +176,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                 walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
         }
         if (prev_n != 0) // the previous tile's matches: reserved before this tile's DMA, stored now
-            finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), park_cnt((it & 1u) ^ 1u),
-                                 prev_n, reserved, it);
+            finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
         ++it;
         if (MODE == 5) {
             const unsigned long long x = stamp();
@@ -182,13 +189,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     if (MODE != 1 && tb.stage_cap != 0 && it != 0) { // what the last tile left parked
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        uint32_t prev_n = __builtin_amdgcn_readfirstlane(*park_cnt((it & 1u) ^ 1u));
+        const uint32_t pp = (it & 1u) ^ 1u;
+        uint32_t prev_n = __builtin_amdgcn_readfirstlane(*park_cnt(pp)) - seen[pp];
         prev_n = prev_n < tb.stage_cap ? prev_n : tb.stage_cap;
         if (prev_n != 0) {
             unsigned long long reserved = 0;
             if (tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
-            finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), park_cnt((it & 1u) ^ 1u),
-                                 prev_n, reserved, it);
+            finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
         }
     }
     if (MODE == 5 && a.stamps != nullptr && lane == 0) {
