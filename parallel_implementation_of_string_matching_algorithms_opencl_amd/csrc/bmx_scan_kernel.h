@@ -142,8 +142,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         }
 
         const uint64_t tn = t + gridDim.x;
-        if (issues && tn < a.tile_end && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x))
-            issue_tile(tn, cur ? buf0 : buf1);
+        // MODE 6 (staggered issue): the upper half of the waves walks first and issues afterwards
+        const bool issue_late = MODE == 6 && wave >= (uint32_t)(BLOCK / 128);
+        const bool issue_now = issues && tn < a.tile_end && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x);
+        if (issue_now && !issue_late) issue_tile(tn, cur ? buf0 : buf1);
 
         if (MODE == 5) {
             const unsigned long long x = stamp();
@@ -175,6 +177,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             else
                 walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
         }
+        if (issue_now && issue_late) issue_tile(tn, cur ? buf0 : buf1);
         if (prev_n != 0) // the previous tile's matches: reserved before this tile's DMA, stored now
             finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
         ++it;

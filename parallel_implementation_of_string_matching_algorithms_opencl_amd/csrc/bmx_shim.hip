@@ -116,6 +116,7 @@ const Variant g_variants[] = {
     BMX_TILE(1024, 36, 2, 0, 3),        // 25: 4-gram walker, 36 KiB tiles, two workgroups per CU
     BMX_TILE(1024, 68, 2, 0, 4),        // 26: default geometry, byte-wise walker with two windows in flight
     BMX_TILE(1024, 68, 2, 0, 5),        // 27: byte-wise walker on an 8-bit bad-symbol table (m <= 255 only)
+    BMX_TILE(1024, 68, 2, 6, 0),        // 28: default kernel, half of the waves issue their DMA share AFTER their walk
 };
 constexpr int N_PRODUCT_VARIANTS = 12;
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
