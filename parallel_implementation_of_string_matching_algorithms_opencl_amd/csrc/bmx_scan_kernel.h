@@ -115,8 +115,20 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             st_prev = x;
         }
         __syncthreads();
+        if (MODE == 5) {
+            const unsigned long long x = stamp();
+            st_bar += x - st_prev;
+            st_prev = x;
+        }
+
+        const uint64_t tn = t + gridDim.x;
+        // MODE 6 (staggered issue): the upper half of the waves walks first and issues afterwards
+        const bool issue_late = MODE == 6 && wave >= (uint32_t)(BLOCK / 128);
+        const bool issue_now = issues && tn < a.tile_end && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x);
+        if (issue_now && !issue_late) issue_tile(tn, cur ? buf0 : buf1);
         // Matches parked while the PREVIOUS tile was walked: reserve their slots now (one global atomic by
-        // one thread, not waited for), park this tile's matches in the other buffer meanwhile.
+        // one thread, not waited for; after the DMA issue, which must not wait for the LDS read here), park
+        // this tile's matches in the other buffer meanwhile.
         uint32_t prev_n = 0;
         unsigned long long reserved = 0;
         if (MODE != 1 && tb.stage_cap != 0) {
@@ -135,17 +147,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             tb.stage_cnt = park_cnt(it & 1u);
             tb.stage_seen = seen[it & 1u];
         }
-        if (MODE == 5) {
-            const unsigned long long x = stamp();
-            st_bar += x - st_prev;
-            st_prev = x;
-        }
-
-        const uint64_t tn = t + gridDim.x;
-        // MODE 6 (staggered issue): the upper half of the waves walks first and issues afterwards
-        const bool issue_late = MODE == 6 && wave >= (uint32_t)(BLOCK / 128);
-        const bool issue_now = issues && tn < a.tile_end && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x);
-        if (issue_now && !issue_late) issue_tile(tn, cur ? buf0 : buf1);
 
         if (MODE == 5) {
             const unsigned long long x = stamp();
