@@ -736,9 +736,30 @@ int bmx_edit_distance_device(bmx_ctx *ctx, const void *d_a, uint64_t la, const v
     HIPCHK(hipSetDevice(ctx->device));
     const EdVariant &v = g_ed_variants[ctx->ed_variant & ~ED_FLAGS];
     if (v.band && !(ctx->ed_variant & ED_FLAGS)) {
+        // The distance is symmetric and the pipeline is not: a row costs a step of every band, a column only its
+        // share of one more band's lag (0.5 vs lag / (128 C) = 0.23 steps per character).  So the longer string
+        // provides the columns; and with the default variant the band width is the one the step model likes best
+        // (step ~ 25 + 3 C instructions, lb/2 + bands * lag / 2 of them: C = 6 at 64k x 64k, C = 3 at 8k x 128k).
+        if (lb > la) {
+            std::swap(d_a, d_b);
+            std::swap(la, lb);
+        }
+        const EdVariant *pick = &v;
+        if (ctx->ed_variant == 0) {
+            double best = 0.0;
+            for (const EdVariant &c : g_ed_variants) {
+                if (!c.band) continue;
+                const double bands = (double)((la + 64 * c.band_c - 1) / (64 * c.band_c));
+                const double t = ((double)lb / 2 + bands * ED_BAND_LAG / 2) * (25.0 + 3.0 * c.band_c);
+                if (best == 0.0 || t < best) {
+                    best = t;
+                    pick = &c;
+                }
+            }
+        }
         uint32_t h = 0;
         bool used = false;
-        const int rc = ed_band_run(ctx, v, d_a, la, d_b, lb, stream, &h, &used);
+        const int rc = ed_band_run(ctx, *pick, d_a, la, d_b, lb, stream, &h, &used);
         if (rc != BMX_OK) return rc;
         if (used) {
             *distance = h;
