@@ -929,7 +929,15 @@ int bmx_text_upload(bmx_ctx *ctx, const char *text, uint64_t n, void **d_text_ou
     if (!ctx || !d_text_out || (n > 0 && !text)) return BMX_ERR_ARG;
     int rc = bmx_device_alloc(ctx, n, d_text_out);
     if (rc != BMX_OK) return rc;
-    if (n) HIPCHK(hipMemcpy(*d_text_out, text, n, hipMemcpyHostToDevice));
+    if (n) {
+        const hipError_t e = hipMemcpy(*d_text_out, text, n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_err("bmx_text_upload: %s", hipGetErrorString(e));
+            (void)hipFree(*d_text_out);
+            *d_text_out = nullptr;
+            return BMX_ERR_HIP;
+        }
+    }
     return BMX_OK;
 }
 
