@@ -240,43 +240,60 @@ def main():
     m = spec.m
 
     # Two searches in flight (--in-flight 2): each has its own context (device counters, pinned status
-    # word, event ring), output buffer and -- for N > 1 -- slot exchange; they alternate on ONE stream,
-    # so while the host waits for search k and launches search k+2, the GPU is already scanning for
-    # search k+1.  A step is still one complete search whose result the host collects (one step later).
+    # word, event ring), output buffer, stream and -- for N > 1 -- slot exchange.  Search k+1's scan waits
+    # for the end of search k's SCAN kernel only (bmx_stream_wait_last_scan), so it runs while search k's
+    # ordering kernel -- and at N > 1 the all-gather and the merge of its slots -- finish on the other
+    # stream, and while the host waits for search k and launches search k+2: ordering, exchange and host are
+    # off the critical path.  Two scans never overlap.  A step is still one complete search whose result
+    # the host collects (one step later).
     start, length, n_own = shard.shard_extent(spec.n, m, world, rank)
     tables = host.build_tables(pat)  # host tables once, like BoyreMoore.cpp:150-190 (outside its timer too)
     lanes = []
-    for li in range(max(1, args.in_flight)):
+    n_lanes = max(1, args.in_flight)
+    d_text = None
+    for li in range(n_lanes):
         c = host.Context(local_rank)
         if args.variant >= 0:
             c.set_variant(args.variant)
-        if li == 0:
+        if d_text is None:
             d_text = spec.device_text(c, start, length, device=dev)
-        if multi:
-            x = shard.SlotExchange(c, world, rank, dev, slot=SLOT, via_host=rehearse)  # [count | offsets...] over RCCL
-            o = x.out
-        else:
-            x = None
-            o = torch.zeros(SLOT, dtype=torch.int64, device=dev)
-        q = c.prepare(d_text, pat, o, n=length, n_own=n_own, base_offset=start, tables=tables)
-        lanes.append({"ctx": c, "xchg": x, "out": o, "query": q, "pending": False, "result": None, "started": 0})
+            torch.cuda.synchronize()  # the lanes' streams start behind the text
+        stream = torch.cuda.Stream(dev) if n_lanes > 1 else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(stream):
+            if multi:
+                x = shard.SlotExchange(c, world, rank, dev, slot=SLOT, via_host=rehearse)  # [count | offsets...] over RCCL
+                o = x.out
+            else:
+                x = None
+                o = torch.zeros(SLOT, dtype=torch.int64, device=dev)
+            q = c.prepare(d_text, pat, o, n=length, n_own=n_own, base_offset=start, tables=tables)  # binds the stream
+        lanes.append({"ctx": c, "xchg": x, "out": o, "query": q, "pending": False, "result": None, "started": 0,
+                      "stream": stream})
+    torch.cuda.synchronize()
     ctx = lanes[0]["ctx"]
+    last = {"lane": None}  # the lane whose scan was enqueued most recently
 
     def collect(lane):
         if lane["pending"]:
-            if multi:
-                lane["result"] = lane["xchg"].finish(lane["query"])  # polls the pinned totals of the merge kernel
-            else:
-                lane["result"] = lane["out"][:lane["query"].finish()]  # polls the pinned status word
+            with torch.cuda.stream(lane["stream"]):
+                if multi:
+                    lane["result"] = lane["xchg"].finish(lane["query"])  # polls the pinned totals of the merge kernel
+                else:
+                    lane["result"] = lane["out"][:lane["query"].finish()]  # polls the pinned status word
             lane["pending"] = False
 
     def step(i):
         lane = lanes[i % len(lanes)]
         collect(lane)  # the search this lane started len(lanes) steps ago
-        if multi:
-            lane["xchg"].start(lane["query"])  # scan + order + all-gather + merge
-        else:
-            lane["query"].enqueue()  # scan + order
+        with torch.cuda.stream(lane["stream"]):
+            prev = last["lane"]
+            if prev is not None and prev is not lane:
+                prev["ctx"].stream_wait_last_scan(lane["stream"])  # two scans never overlap
+            if multi:
+                lane["xchg"].start(lane["query"])  # scan, then order + all-gather + merge under the NEXT lane's scan
+            else:
+                lane["query"].enqueue()  # scan, then order under the next lane's scan
+            last["lane"] = lane
         lane["pending"] = True
         lane["started"] += 1
 

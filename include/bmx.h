@@ -141,6 +141,12 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
  * exchange below does -- has then seen the unordered list and must take it again. */
 int bmx_last_search_sorted(bmx_ctx *ctx);
 
+/* Make `stream` wait until the SCAN kernel of the most recent enqueue on ctx has finished (not its
+ * ordering kernel, not whatever the caller put behind it): a second context can then start its own
+ * scan on `stream` back to back with this one while this context's ordering and exchange still run
+ * on their own stream.  bench.py keeps two searches in flight this way. */
+int bmx_stream_wait_last_scan(bmx_ctx *ctx, void *stream);
+
 /* ---- multi-GPU exchange helpers (the collective itself is RCCL, outside) ------ */
 
 /* Copy the match count of the most recent enqueue on ctx to d_dst[0], on-stream

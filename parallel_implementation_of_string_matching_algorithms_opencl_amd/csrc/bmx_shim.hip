@@ -366,6 +366,15 @@ int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6])
 
 int bmx_last_search_sorted(bmx_ctx *ctx) { return ctx && ctx->last_sorted ? 1 : 0; }
 
+int bmx_stream_wait_last_scan(bmx_ctx *ctx, void *stream_v)
+{
+    if (!ctx) return BMX_ERR_ARG;
+    if (ctx->n_timed == 0) return BMX_OK; // nothing enqueued yet
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream_v, ctx->ev1[(ctx->n_timed - 1) % bmx_ctx::EV_RING], 0));
+    return BMX_OK;
+}
+
 float bmx_last_scan_ms(bmx_ctx *ctx)
 {
     float ms = -1.0f;

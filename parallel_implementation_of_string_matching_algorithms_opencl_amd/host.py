@@ -57,6 +57,7 @@ SYMBOLS = [
                                             C.c_int32, _i32p, _i32p, C.c_void_p, C.c_uint64, C.c_void_p]),
     ("bmx_search_device_finish", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, _u64p, C.c_void_p]),
     ("bmx_last_search_sorted", C.c_int, [C.c_void_p]),
+    ("bmx_stream_wait_last_scan", C.c_int, [C.c_void_p, C.c_void_p]),
     ("bmx_count_to_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("bmx_merge_gathered_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_uint64,
                                             C.c_void_p, C.c_uint64, C.c_void_p]),
@@ -306,6 +307,10 @@ class Context:
         _check(lib().bmx_scan_geometry(self._h, m, g), "bmx_scan_geometry")
         return {"grid": int(g[0]), "block": int(g[1]), "tile_bytes": int(g[2]), "lds_bytes": int(g[3]),
                 "seg": int(g[4]), "kind": ("workgroup-tile", "wave-stream", "workgroup-ring")[int(g[5])]}
+
+    def stream_wait_last_scan(self, stream) -> None:
+        """Make ``stream`` (a torch.cuda.Stream) wait for the scan kernel of this context's latest enqueue."""
+        _check(lib().bmx_stream_wait_last_scan(self._h, C.c_void_p(stream.cuda_stream)), "bmx_stream_wait_last_scan")
 
     def last_search_sorted(self) -> bool:
         """Did the last finish() have to sort (the list was unordered until then)?"""

@@ -96,11 +96,21 @@ class SlotExchange:
         """Enqueue scan, ordering, all-gather and merge; returns without waiting.  Another
         SlotExchange (with its own Context) may be started before this one is finished: the
         collectives are issued in the same order on every rank."""
+        self.start_scan(query)
+        self.start_exchange()
+
+    def start_scan(self, query):
+        """Scan + ordering + the count into the slot header, on the current stream."""
+        query.enqueue()
+        self.ctx.count_to_device(self.buf)
+
+    def start_exchange(self):
+        """All-gather of the slots + merge, behind :meth:`start_scan` on the current stream.  (A caller
+        that runs the next search on ANOTHER stream, released by an event recorded between the two
+        calls, overlaps this exchange with that search's scan: bench.py does.)"""
         import torch
         import torch.distributed as dist
 
-        query.enqueue()
-        self.ctx.count_to_device(self.buf)
         if self.via_host:
             h = self.buf.cpu()
             hg = torch.empty(self.world * (self.slot + 1), dtype=torch.int64)
