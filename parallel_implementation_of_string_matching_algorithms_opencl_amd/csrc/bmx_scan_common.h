@@ -75,7 +75,7 @@ __device__ __forceinline__ void dma16(const uint8_t *gsrc_lane, const uint8_t *l
 // offset to report.  Every match goes to the unordered list (always complete up
 // to cap: the fallback for dense results) and to its position bucket, from which
 // order_kernel writes the ascending list without a sort.
-__device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint64_t pos)
+__device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint64_t pos, bool feed_buckets = true)
 {
     const uint64_t active = __ballot(1);
     const uint32_t lane = __lane_id();
@@ -87,6 +87,10 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint
     const uint64_t slot = base + rank;
     if (a.out != nullptr) {
         if (slot < a.cap) a.out[slot] = pos;
+        if (!feed_buckets) { // the caller knows the result is dense: one round trip less per call
+            *a.bucket_overflow = 1u;
+            return;
+        }
         const uint32_t b = (uint32_t)(local >> a.bucket_shift);
         const uint32_t s = atomicAdd(&a.bucket_cnt[b], 1u);
         if (s < (uint32_t)ORDER_BUCKET_CAP)
@@ -142,7 +146,9 @@ __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &t
             return;
         }
     }
-    emit_hit(a, astart - a.first, astart + a.out_bias);
+    // the parking buffer is full (or there is none): more than stage_cap matches in this tile outgrow the
+    // position buckets anyway
+    emit_hit(a, astart - a.first, astart + a.out_bias, tb.stage_cap == 0);
 }
 
 // Second half of an append (all threads of the workgroup, `n` > 0 matches of the tile at `tile_off`

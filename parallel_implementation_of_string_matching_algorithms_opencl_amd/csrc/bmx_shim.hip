@@ -233,6 +233,11 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical)
             ++distinct;
         }
     if (distinct > 8) return 0;
+    // sigma^m small = matches every few bytes on a text over the pattern's alphabet (binary, m = 6: one position
+    // in 64): what matters then is room to park them, and the default geometry has four times variant 2's
+    double expect = 1.0;
+    for (int i = 0; i < m && expect < 1e6; ++i) expect *= distinct;
+    if (expect < 128.0) return 0;
     return canonical && m >= 10 && lds_bytes_for(g_variants[VARIANT_QGRAM], m) <= LDS_PER_CU ? VARIANT_QGRAM : 2;
 }
 
