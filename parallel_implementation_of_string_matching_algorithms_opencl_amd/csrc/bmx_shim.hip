@@ -117,6 +117,8 @@ const Variant g_variants[] = {
     BMX_TILE(1024, 68, 2, 0, 4),        // 26: default geometry, byte-wise walker with two windows in flight
     BMX_TILE(1024, 68, 2, 0, 5),        // 27: byte-wise walker on an 8-bit bad-symbol table (m <= 255 only)
     BMX_TILE(1024, 68, 2, 6, 0),        // 28: default kernel, half of the waves issue their DMA share AFTER their walk
+    BMX_TILE(1024, 76, 2, 0, 0),        // 29: 76 KiB tiles, room for 512 parked matches only (picked automatically for
+                                        //     patterns over more than 8 distinct symbols, m >= 4)
 };
 constexpr int N_PRODUCT_VARIANTS = 12;
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
@@ -212,6 +214,7 @@ int blocks_per_cu_for(const bmx_ctx *ctx, const Variant &v, int32_t m)
 uint32_t lds_bytes_for(const Variant &v, int32_t m);
 
 constexpr int VARIANT_QGRAM = 24;
+constexpr int VARIANT_BIG_TILE = 29; // 76 KiB tiles: +2 % on large alphabets, but room for 512 parked matches per tile only
 
 // `canonical`: the shift tables in use are the ones bmx_build_tables makes (always so when the caller
 // passes none).  The 4-gram walker skips with its own table and only leaves a verified window with
@@ -232,7 +235,8 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical)
             seen[(unsigned char)pat[i]] = true;
             ++distinct;
         }
-    if (distinct > 8) return 0;
+    if (distinct > 8) // sparse by nature (9^-4 and less): the larger tile
+        return lds_bytes_for(g_variants[VARIANT_BIG_TILE], m) <= LDS_PER_CU ? VARIANT_BIG_TILE : 0;
     // sigma^m small = matches every few bytes on a text over the pattern's alphabet (binary, m = 6: one position
     // in 64): what matters then is room to park them, and the default geometry has four times variant 2's
     double expect = 1.0;

@@ -14,7 +14,7 @@ from parallel_implementation_of_string_matching_algorithms_opencl_amd import cor
 
 pytestmark = pytest.mark.gpu
 
-PRODUCT_VARIANTS = list(range(12)) + [20, 21, 22, 23, 24, 25, 26, 27]  # bmx_shim.hip: the others are timing experiments
+PRODUCT_VARIANTS = list(range(12)) + [20, 21, 22, 23, 24, 25, 26, 27, 28, 29]  # bmx_shim.hip: the others are timing experiments
 QGRAM_VARIANTS = [24, 25]  # 4-gram walker
 
 
