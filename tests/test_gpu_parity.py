@@ -507,3 +507,47 @@ def test_dense_results_short_patterns(ctx, port):
                 assert np.array_equal(got, port.search(text, pat)), (v, alpha, m, n)
     finally:
         ctx.set_variant(0)
+
+
+def test_two_searches_in_flight_on_two_streams(port):
+    """Two contexts alternate, each on its own stream; a search's scan is released by the end of the
+    other context's SCAN kernel (bmx_stream_wait_last_scan), its ordering kernel runs under the next
+    scan.  Different patterns, so a mixed-up buffer or count would show."""
+    import torch
+
+    rng = np.random.default_rng(61)
+    text = (rng.integers(0, 95, 6 << 20) + 32).astype(np.uint8)
+    pats = [text[1000:1016].tobytes(), text[2_000_000:2_000_009].tobytes()]
+    for k, pat in enumerate(pats):
+        for p in rng.integers(0, text.size - 16, 300 + 100 * k):
+            text[p:p + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
+    want = [port.search(text, pat) for pat in pats]
+    dev = torch.device("cuda", 0)
+    d_text = torch.from_numpy(text).to(dev)
+    torch.cuda.synchronize()
+    lanes = []
+    for pat in pats:
+        c = host.Context(0)
+        s = torch.cuda.Stream(dev)
+        out = torch.zeros(1 << 14, dtype=torch.int64, device=dev)
+        with torch.cuda.stream(s):
+            q = c.prepare(d_text, pat, out, tables=host.build_tables(pat))
+        lanes.append((c, s, out, q))
+    pending = [False, False]
+    prev = None
+    for i in range(12):
+        k = i & 1
+        c, s, out, q = lanes[k]
+        if pending[k]:
+            n = q.finish()
+            assert np.array_equal(out[:n].cpu().numpy().astype(np.uint64), want[k]), i
+        with torch.cuda.stream(s):
+            if prev is not None:
+                lanes[prev][0].stream_wait_last_scan(s)
+            q.enqueue()
+        pending[k] = True
+        prev = k
+    for k in (0, 1):
+        n = lanes[k][3].finish()
+        assert np.array_equal(lanes[k][2][:n].cpu().numpy().astype(np.uint64), want[k])
+        lanes[k][0].close()
