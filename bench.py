@@ -3,8 +3,16 @@
 4 GiB of synthetic ASCII per MI355X, at 1/2/4/8 GPUs.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N --steps K --warmup W          (plain: this process starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+Launched plainly with --gpus N > 1 (no WORLD_SIZE in the environment) the process is only a
+parent: before anything touches a GPU it starts N fresh children of this script, one rank per GPU
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), lets rank 0's JSON line
+through on its own stdout and exits with the worst child's return code -- the one-host-process-
+drives-all-work-items shape of the reference (BoyreMoore.cpp:273-280) without ever replacing a
+process that holds the GPU.
 
 One "step" = one pass of the hot path over the resident text: Boyer-Moore scan
 kernel + ordering of the match list + the count read back by the host, and for
@@ -34,6 +42,71 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--gib-per-gpu", type=float, default=4.0)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg3b", "ed64k", "sa2m"])
+    ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="searches in flight (each with its own context and output buffer); 1 = strictly one at a time")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the N > 1 code path (RCCL process group, slot all-gather, merge) even with one rank: "
+                         "a 1-GPU check of the calls the 2/4/8-GPU runs make")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks all on cuda:0 with the exchange staged through host memory on gloo "
+                         "(RCCL refuses duplicate devices): exercises the multi-rank code path on a 1-GPU box; "
+                         "its numbers mean nothing")
+    return ap.parse_args(argv)
+
+
+def self_launch(n_ranks: int) -> int:
+    """Parent of a plain `python bench.py --gpus N`: start the N ranks as fresh child processes (this
+    process never initialises a GPU, imports no torch), wait, return the worst return code.  A rank that
+    fails takes the others down with it (their exact PIDs) instead of leaving them in a collective."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "WORLD_SIZE": str(n_ranks),
+                    "LOCAL_WORLD_SIZE": str(n_ranks), "RANK": str(r), "LOCAL_RANK": str(r),
+                    "BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, failed_at = 0, None
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = rc if worst == 0 else worst
+                failed_at = failed_at or time.monotonic()
+        if failed_at is not None and live and time.monotonic() - failed_at > 20.0:
+            for p in live:  # the others are stuck in a collective with a dead peer
+                p.kill()
+        time.sleep(0.05)
+    return worst
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _early = parse_args()
+    if _early.gpus > 1:  # before torch is even imported: the parent stays off the GPU
+        sys.exit(self_launch(_early.gpus))
 
 import numpy as np
 import torch
@@ -180,33 +253,14 @@ def bench_suffix_array(args, dev, local_rank):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--gib-per-gpu", type=float, default=4.0)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg3b", "ed64k", "sa2m"])
-    ap.add_argument("--variant", type=int, default=-1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=12.0)
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="searches in flight (each with its own context and output buffer); 1 = strictly one at a time")
-    ap.add_argument("--force-exchange", action="store_true",
-                    help="run the N > 1 code path (RCCL process group, slot all-gather, merge) even with one rank: "
-                         "a 1-GPU check of the calls the 2/4/8-GPU runs make")
-    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="N > 1 ranks all on cuda:0 with the exchange staged through host memory on gloo "
-                         "(RCCL refuses duplicate devices): exercises the multi-rank code path on a 1-GPU box; "
-                         "its numbers mean nothing")
-    args = ap.parse_args()
+    args = parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if world != args.gpus:  # (a plain launch with --gpus N never gets here: self_launch above)
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment", file=sys.stderr)
         sys.exit(2)
     multi = world > 1 or args.force_exchange  # take the distributed code path
     rehearse = args.rehearse_on_one_gpu and world > 1
@@ -344,6 +398,9 @@ def main():
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "ranks_seen": dist.get_world_size() if multi else 1,
+        "launch": "self-launched ranks" if os.environ.get("BENCH_SELF_LAUNCHED") else
+                  ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process"),
         "config": {"workload": spec.name, "text_bytes_total": spec.n, "text_bytes_per_gpu": n_own,
                    "pattern_bytes": m, "alphabet": "printable-95" if spec.kind == 0 else "ACGT",
                    "matches": int(result.size), "searches_in_flight": len(lanes), "sharding": f"{world} contiguous shard(s) + {m - 1} B halo",

@@ -193,9 +193,13 @@ int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6]);
  * launch, 8 words per wave {issue, walk, dma_wait, barrier_wait, tiles, 0, 0, 0}.
  * Returns the number of words copied. */
 int bmx_scan_stamps(bmx_ctx *ctx, uint64_t *out, uint64_t max_words);
-/* Tuning knob for experiments: -1 = automatic choice (the state of a new context: the default
- * kernel, or the 4-gram walker for patterns over at most 8 distinct symbols), >= 0 = that kernel. */
+/* Kernel choice: -1 = automatic (the state of a new context: by pattern length and alphabet),
+ * >= 0 = that slot of the kernel table.  libbmx.so contains only kernels whose match lists are
+ * valid and parity-tested; every other slot (schedules that lost, timing-only builds) exists in
+ * libbmx_exp.so alone (same sources, -DBMX_EXPERIMENTS, used by tools/) and is refused here
+ * with BMX_ERR_ARG.  bmx_variant_count() = number of slots (built or not). */
 int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu);
+int bmx_variant_count(void);
 
 /* ---- edit distance: the reference's second algorithm ------------ */
 

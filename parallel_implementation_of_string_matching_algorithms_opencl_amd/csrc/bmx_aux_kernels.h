@@ -46,6 +46,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
     __shared__ uint32_t wave_total[ORDER_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long total = *count;
+    const uint32_t scan_err = bucket_overflow[1]; // raised by finish_parked (bmx_scan_common.h): the list is incomplete
     const bool ordered = out != nullptr && *bucket_overflow == 0 && total <= cap; // block-uniform
 
     uint4 *cnt4 = reinterpret_cast<uint4 *>(bucket_cnt);
@@ -98,11 +99,14 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
         status[1] = needs_sort;
         // what bmx_count_to_device publishes: a list that is not ordered yet counts as larger than any slot
         status[2] = needs_sort ? (total | (1ull << 62)) : total;
+        status[3] = scan_err;
         *count = 0;
-        *bucket_overflow = 0;
+        bucket_overflow[0] = 0;
+        bucket_overflow[1] = 0;
         // the host polls host_status[2] (pinned, fine-grained) for this search's sequence number
         host_status[0] = total;
         host_status[1] = needs_sort;
+        host_status[3] = scan_err;
         __hip_atomic_store(&host_status[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     cnt4[2 * tid] = make_uint4(0, 0, 0, 0);

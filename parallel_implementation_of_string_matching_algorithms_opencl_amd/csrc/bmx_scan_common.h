@@ -44,6 +44,8 @@ struct ScanArgs {
     uint32_t *bucket_cnt;    // ORDER_BUCKETS counters
     uint64_t *bucket_store;  // ORDER_BUCKETS x ORDER_BUCKET_CAP offsets
     uint32_t *bucket_overflow; // set to 1 when a bucket is full
+    uint32_t *err;           // set to 1 when a workgroup gave up waiting for its slot reservation (finish_parked):
+                             // order_kernel hands it to the host, bmx_search_device_finish returns BMX_ERR_HIP
     uint32_t bucket_shift;
     unsigned long long *stamps; // MODE 5 only (diagnostic build): per-wave cycle sums, 8 words per wave
     uint32_t m;
@@ -169,10 +171,22 @@ __device__ __forceinline__ void finish_parked(const ScanArgs &a, const LdsTables
         base_w[1] = (uint32_t)(reserved >> 32);
         *flag = ticket; // LDS keeps a wave's stores in order: the base is there when the ticket is
     }
+    // Thread 0 always gets here, so the wait is bounded by its global atomic's round trip.  The bound below
+    // (~1 s) only exists so that a wave can never spin for ever: a waiter that reaches it raises the error
+    // word (the host returns BMX_ERR_HIP for this search) and drops its share of the stores -- no trap, the
+    // grid drains normally.  Tickets only grow, so a flag that arrives late matches no later wait.
     uint32_t spins = 0;
+    bool gave_up = false;
     while (*flag != ticket) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 24)) __builtin_trap(); // thread 0 always gets here: a bound, not a path
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24)) {
+            gave_up = true;
+            break;
+        }
+    }
+    if (gave_up) {
+        *a.err = 1u;
+        return;
     }
     if (a.out == nullptr) return;
     const unsigned long long base = ((unsigned long long)base_w[1] << 32) | base_w[0];

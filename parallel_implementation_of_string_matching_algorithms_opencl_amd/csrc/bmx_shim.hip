@@ -68,11 +68,24 @@ struct Variant {
     int nbuf;
     int loaders; // kind 0: waves that only issue DMA
     bool stamps; // diagnostic build that writes s_memtime sums (bmx_scan_stamps)
-    bool qgram;  // 4-gram walker: 16 KiB shift table in LDS, needs the canonical shift tables
-    void (*kernel)(const bmx::ScanArgs);
+    bool qgram;  // 4-gram walker: shift table in LDS, needs the canonical shift tables
+    void (*kernel)(const bmx::ScanArgs); // nullptr: this slot is not built into this library
     void (*kernel_short)(const bmx::ScanArgs);
 };
 
+// The slot numbers are stable (tools/ and the notes in DESIGN.md refer to them), but the PRODUCT library
+// (libbmx.so) only contains the kernels the automatic choice can pick plus their parity-tested alternates;
+// every other slot -- schedules that lost (ring, wave streams, loader waves, other geometries) and the
+// timing-only builds whose match lists are NOT valid (DMA only, walkers only, one walking wave) -- exists
+// only in libbmx_exp.so, the same sources compiled with -DBMX_EXPERIMENTS for tools/ (BMX_LIB=exp).
+// bmx_set_variant() refuses a slot that is not built: no caller of the shipped C ABI can select a kernel
+// that returns a wrong match list (tests/test_gpu_parity.py::test_product_library_accepts_only_its_variants).
+#define BMX_ABSENT {0, 0, 0, 0, 0, false, false, nullptr, nullptr}
+#ifdef BMX_EXPERIMENTS
+#define BMX_EXP(...) __VA_ARGS__
+#else
+#define BMX_EXP(...) BMX_ABSENT
+#endif
 #define BMX_TILE(B, S, AUX, MODE, W) BMX_TILE_L(B, S, AUX, MODE, W, 0)
 #define BMX_TILE_L(B, S, AUX, MODE, W, L) \
     {0, B, S, 2, L, (MODE) == 5, (W) == 3, bmx::scan_kernel<B, S, AUX, MODE, W, L>, bmx::scan_kernel<B, S, AUX, MODE, 6, L>}
@@ -84,43 +97,43 @@ struct Variant {
 #define BMX_WAVE(WV, S, AUX, MODE, D, NB)                                                      \
     {1, (WV) * 64, S, NB, 0, false, false, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>}
 const Variant g_variants[] = {
-    // ---- products (every one parity-tested by tests/test_gpu_parity.py) ----
-    BMX_TILE(1024, 68, 2, 0, 0),        // 0: default -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
-    BMX_TILE(1024, 68, 2, 0, 2),        // 1: same tile, skip-loop walker
-    BMX_TILE_W32(1024, 36, 2, 0, 2),    // 2: skip-loop walker, 36 KiB tiles, TWO workgroups = 32 waves per CU
-                                        //    (picked automatically for small alphabets)
-    BMX_TILE(768, 100, 2, 0, 0),        // 3
-    BMX_TILE(256, 132, 2, 0, 0),        // 4: two workgroups per CU
-    BMX_TILE(256, 132, 0, 0, 0),        // 5: default cache policy -- the first kernel of round 1
-    BMX_WAVE(16, 68, 2, 0, 2, 2),       // 6: wave streams, two buffers per wave, speculation depth 2
-    BMX_WAVE(8, 100, 2, 0, 2, 3),       // 7: wave streams, three buffers per wave
-    BMX_WAVE(12, 68, 2, 0, 1, 3),       // 8: wave streams, no speculation
-    BMX_RING(1024, 52, 2, false, 0),    // 9: three-buffer ring, walk then issue
-    BMX_RING(1024, 52, 2, true, 0),     // 10: ring, skip-loop walker
-    BMX_TILE_L(1024, 76, 2, 0, 0, 2),   // 11: 2 loader waves + 14 walker waves
+    BMX_TILE(1024, 68, 2, 0, 0),                 // 0: PRODUCT -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
+                                                 //    (the automatic choice for m < 4 and for dense small-alphabet results)
+    BMX_TILE(1024, 68, 2, 0, 2),                 // 1: PRODUCT -- same tile, skip-loop walker
+    BMX_TILE_W32(1024, 36, 2, 0, 2),             // 2: PRODUCT -- skip-loop walker, 36 KiB tiles, TWO workgroups = 32 waves
+                                                 //    per CU (picked automatically for small alphabets, m < 10)
+    BMX_EXP(BMX_TILE(768, 100, 2, 0, 0)),        // 3
+    BMX_EXP(BMX_TILE(256, 132, 2, 0, 0)),        // 4: two workgroups per CU
+    BMX_EXP(BMX_TILE(256, 132, 0, 0, 0)),        // 5: default cache policy -- the first kernel of round 1
+    BMX_EXP(BMX_WAVE(16, 68, 2, 0, 2, 2)),       // 6: wave streams, two buffers per wave, speculation depth 2
+    BMX_EXP(BMX_WAVE(8, 100, 2, 0, 2, 3)),       // 7: wave streams, three buffers per wave
+    BMX_EXP(BMX_WAVE(12, 68, 2, 0, 1, 3)),       // 8: wave streams, no speculation
+    BMX_EXP(BMX_RING(1024, 52, 2, false, 0)),    // 9: three-buffer ring, walk then issue
+    BMX_EXP(BMX_RING(1024, 52, 2, true, 0)),     // 10: ring, skip-loop walker
+    BMX_EXP(BMX_TILE_L(1024, 76, 2, 0, 0, 2)),   // 11: 2 loader waves + 14 walker waves
     // ---- timing experiments (parts of the kernel in isolation; match lists are NOT valid) ----
-    BMX_TILE(1024, 68, 2, 1, 0),        // 12: DMA only
-    BMX_TILE(1024, 68, 2, 2, 0),        // 13: walkers only
-    BMX_TILE(1024, 68, 2, 5, 0),        // 14: s_memtime stamps per tile phase (valid matches; bmx_scan_stamps)
-    BMX_RING(1024, 52, 2, false, 5),    // 15: stamps, ring kernel
-    BMX_WAVE(8, 100, 2, 1, 2, 3),       // 16: DMA only, wave streams
-    BMX_WAVE(8, 100, 2, 2, 2, 3),       // 17: walkers only, wave streams
-    BMX_TILE(1024, 68, 2, 3, 0),        // 18: only wave 0 of each workgroup walks
-    BMX_TILE_L(1024, 68, 2, 1, 0, 1),   // 19: DMA only through ONE loader wave
-    // ---- more products under test (valid match lists) ----
-    BMX_TILE(512, 68, 2, 0, 0),         // 20: two workgroups of 8 waves per CU, 34 KiB tiles
-    BMX_TILE(512, 76, 2, 0, 0),         // 21: same, 38 KiB tiles
-    BMX_TILE(512, 132, 2, 0, 0),        // 22: one workgroup of 8 waves, 66 KiB tiles
-    BMX_TILE_W32(1024, 36, 2, 0, 0),    // 23: variant 2's geometry with the byte-wise walker
-    BMX_TILE(1024, 68, 2, 0, 3),        // 24: default geometry, 4-gram walker (picked automatically for small alphabets)
-    BMX_TILE(1024, 36, 2, 0, 3),        // 25: 4-gram walker, 36 KiB tiles, two workgroups per CU
-    BMX_TILE(1024, 68, 2, 0, 4),        // 26: default geometry, byte-wise walker with two windows in flight
-    BMX_TILE(1024, 68, 2, 0, 5),        // 27: byte-wise walker on an 8-bit bad-symbol table (m <= 255 only)
-    BMX_TILE(1024, 68, 2, 6, 0),        // 28: default kernel, half of the waves issue their DMA share AFTER their walk
-    BMX_TILE(1024, 76, 2, 0, 0),        // 29: 76 KiB tiles, room for 512 parked matches only (picked automatically for
-                                        //     patterns over more than 8 distinct symbols, m >= 4)
+    BMX_EXP(BMX_TILE(1024, 68, 2, 1, 0)),        // 12: DMA only
+    BMX_EXP(BMX_TILE(1024, 68, 2, 2, 0)),        // 13: walkers only
+    BMX_EXP(BMX_TILE(1024, 68, 2, 5, 0)),        // 14: s_memtime stamps per tile phase (valid matches; bmx_scan_stamps)
+    BMX_EXP(BMX_RING(1024, 52, 2, false, 5)),    // 15: stamps, ring kernel
+    BMX_EXP(BMX_WAVE(8, 100, 2, 1, 2, 3)),       // 16: DMA only, wave streams
+    BMX_EXP(BMX_WAVE(8, 100, 2, 2, 2, 3)),       // 17: walkers only, wave streams
+    BMX_EXP(BMX_TILE(1024, 68, 2, 3, 0)),        // 18: only wave 0 of each workgroup walks
+    BMX_EXP(BMX_TILE_L(1024, 68, 2, 1, 0, 1)),   // 19: DMA only through ONE loader wave
+    // ---- more geometries / walkers with valid match lists ----
+    BMX_EXP(BMX_TILE(512, 68, 2, 0, 0)),         // 20: two workgroups of 8 waves per CU, 34 KiB tiles
+    BMX_EXP(BMX_TILE(512, 76, 2, 0, 0)),         // 21: same, 38 KiB tiles
+    BMX_EXP(BMX_TILE(512, 132, 2, 0, 0)),        // 22: one workgroup of 8 waves, 66 KiB tiles
+    BMX_EXP(BMX_TILE_W32(1024, 36, 2, 0, 0)),    // 23: variant 2's geometry with the byte-wise walker
+    BMX_TILE(1024, 68, 2, 0, 3),                 // 24: PRODUCT -- default geometry, 4-gram walker (picked automatically for
+                                                 //     small alphabets, m >= 10)
+    BMX_TILE(1024, 36, 2, 0, 3),                 // 25: PRODUCT -- 4-gram walker, 36 KiB tiles, two workgroups per CU
+    BMX_EXP(BMX_TILE(1024, 68, 2, 0, 4)),        // 26: default geometry, byte-wise walker with two windows in flight
+    BMX_EXP(BMX_TILE(1024, 68, 2, 0, 5)),        // 27: byte-wise walker on an 8-bit bad-symbol table (m <= 255 only)
+    BMX_EXP(BMX_TILE(1024, 68, 2, 6, 0)),        // 28: default kernel, half of the waves issue their DMA share AFTER their walk
+    BMX_TILE(1024, 76, 2, 0, 0),                 // 29: PRODUCT -- 76 KiB tiles, room for 512 parked matches only (picked
+                                                 //     automatically for patterns over more than 8 distinct symbols, m >= 4)
 };
-constexpr int N_PRODUCT_VARIANTS = 12;
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
 
@@ -304,7 +317,7 @@ int bmx_ctx_create(int device, bmx_ctx **out)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_bucket_cnt, bmx::ORDER_BUCKETS * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_bucket_store, (size_t)bmx::ORDER_BUCKETS * bmx::ORDER_BUCKET_CAP * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, 2 * sizeof(uint32_t)); // {bucket overflow, scan error}
     if (e == hipSuccess) e = hipMalloc(&ctx->d_status, 4 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 4 * sizeof(uint64_t), hipHostMallocMapped);
     if (e == hipSuccess) {
@@ -347,18 +360,23 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
 int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu)
 {
     if (!ctx || variant < -1 || variant >= N_VARIANTS || blocks_per_cu < 0) return BMX_ERR_ARG;
+    if (variant >= 0 && g_variants[variant].kernel == nullptr) { // a slot of libbmx_exp.so only
+        set_err("bmx_set_variant: variant %d is not part of this library (experiments: libbmx_exp.so)", variant);
+        return BMX_ERR_ARG;
+    }
     if (variant == -1) { // back to the automatic choice (pick_variant)
         ctx->variant = 0;
         ctx->auto_walker = true;
         ctx->blocks_per_cu = blocks_per_cu;
         return BMX_OK;
     }
-    (void)N_PRODUCT_VARIANTS; // variants >= N_PRODUCT_VARIANTS exist for tools/variant_sweep.py only
     ctx->variant = variant;
     ctx->auto_walker = false;
     ctx->blocks_per_cu = blocks_per_cu;
     return BMX_OK;
 }
+
+int bmx_variant_count(void) { return N_VARIANTS; }
 
 int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6])
 {
@@ -418,7 +436,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     if (!ctx->armed) { // first use, or a previous enqueue failed half way: zero the device counters
         HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(ctx->d_bucket_cnt, 0, bmx::ORDER_BUCKETS * sizeof(uint32_t), stream));
-        HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, 2 * sizeof(uint32_t), stream));
     }
     ctx->armed = false;
 
@@ -454,6 +472,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         a.bucket_cnt = ctx->d_bucket_cnt;
         a.bucket_store = ctx->d_bucket_store;
         a.bucket_overflow = ctx->d_overflow;
+        a.err = ctx->d_overflow + 1;
         a.bucket_shift = 0;
         a.stamps = nullptr;
         a.stage_cap = stage_cap_for(v, m);
@@ -537,6 +556,11 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
     }
     const uint64_t total = ctx->h_status[0];
     const bool needs_sort = ctx->h_status[1] != 0;
+    if (ctx->h_status[3] != 0) { // finish_parked (bmx_scan_common.h): matches were dropped, the list is not the answer
+        set_err("scan kernel: a workgroup waited longer than its bound for a slot reservation; result discarded");
+        if (n_matches) *n_matches = 0;
+        return BMX_ERR_HIP;
+    }
     ctx->last_sorted = needs_sort;
     if (n_matches) *n_matches = total;
     const uint64_t stored = std::min(total, capacity);
@@ -654,7 +678,6 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
         fresh = ctx->ed_ws_shape[0] != la || ctx->ed_ws_shape[1] != lb || ctx->ed_ws_shape[2] != W;
     } else {
         if (ctx->ed_ws) (void)hipFree(ctx->ed_ws);
-    if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
         ctx->ed_ws = nullptr;
         ctx->ed_ws_bytes = 0;
         if (hipMalloc(&ws, bytes) != hipSuccess) {

@@ -24,6 +24,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbmx.so")
+# tools/ only: BMX_LIB=exp loads libbmx_exp.so, the same sources built with -DBMX_EXPERIMENTS (losing schedules and
+# timing-only kernels whose match lists are not valid).  Tests, bench.py and smoke() never set it.
+if os.environ.get("BMX_LIB") == "exp":
+    LIB_PATH = os.path.join(_HERE, "lib", "libbmx_exp.so")
 
 MAX_PATTERN = 512
 BAD_TABLE_SIZE = 128
@@ -69,6 +73,7 @@ SYMBOLS = [
     ("bmx_scan_stamps", C.c_int, [C.c_void_p, _u64p, C.c_uint64]),
     ("bmx_scan_geometry", C.c_int, [C.c_void_p, C.c_int32, _u64p]),
     ("bmx_set_variant", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("bmx_variant_count", C.c_int, []),
     ("bmx_edit_distance", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]),
     ("bmx_edit_distance_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                            C.c_void_p]),

@@ -14,7 +14,9 @@ from parallel_implementation_of_string_matching_algorithms_opencl_amd import cor
 
 pytestmark = pytest.mark.gpu
 
-PRODUCT_VARIANTS = list(range(12)) + [20, 21, 22, 23, 24, 25, 26, 27, 28, 29]  # bmx_shim.hip: the others are timing experiments
+# bmx_shim.hip: the slots built into libbmx.so.  Every other slot (losing schedules, timing-only kernels whose
+# match lists are not valid) exists in libbmx_exp.so only and is refused by bmx_set_variant here.
+PRODUCT_VARIANTS = [0, 1, 2, 24, 25, 29]
 QGRAM_VARIANTS = [24, 25]  # 4-gram walker
 
 
@@ -211,19 +213,41 @@ def test_pattern_lengths_1_99_512(ctx, port):
         assert np.array_equal(dev_search(ctx, text, pat), port.search(text, pat)), m
 
 
-def test_variant_that_does_not_fit_lds_falls_back(ctx, port):
-    """Three 52 KiB buffers + three 512-byte halos exceed the CU's 160 KiB of LDS: an explicitly
-    chosen variant that cannot hold the pattern's halo must fall back to the default kernel."""
+def test_longest_pattern_on_every_product_variant(ctx, port):
+    """m = 512 (BMX_MAX_PATTERN): two tile buffers + two 512-byte halos + the tables are the most LDS a
+    variant asks for; a variant that could not hold them falls back to the default kernel (pick_variant)."""
     rng = np.random.default_rng(12)
     text = (rng.integers(0, 3, 300000) + 97).astype(np.uint8)
     pat = text[777:777 + 512].tobytes()
     text[200000:200512] = np.frombuffer(pat, dtype=np.uint8)
     try:
-        for v in (9, 10, 7):
+        for v in PRODUCT_VARIANTS:
             ctx.set_variant(v)
             assert np.array_equal(dev_search(ctx, text, pat), port.search(text, pat)), v
     finally:
         ctx.set_variant(0)
+
+
+def test_product_library_accepts_only_its_variants(ctx):
+    """The shipped C ABI cannot select a kernel whose match list is not valid: every slot of the kernel
+    table that is not built into libbmx.so is refused with BMX_ERR_ARG, and the accepted ones are exactly
+    the parity-tested PRODUCT_VARIANTS of this file."""
+    n = host.lib().bmx_variant_count()
+    assert n >= 30 and host.LIB_PATH.endswith("libbmx.so")
+    accepted = []
+    try:
+        for v in range(n):
+            try:
+                ctx.set_variant(v)
+                accepted.append(v)
+            except host.BmxError as e:
+                assert e.rc == host.ERR_ARG, v
+        for v in (n, n + 7, -2):
+            with pytest.raises(host.BmxError):
+                ctx.set_variant(v)
+    finally:
+        ctx.set_variant(0)
+    assert accepted == PRODUCT_VARIANTS
 
 
 def test_misaligned_device_pointers(ctx, port):

@@ -157,9 +157,37 @@ def test_bench_multi_rank_path_rehearsal(ctx):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["unit"] == "GB/s"
+    assert line["ranks_seen"] == 2 and line["launch"] == "torch.distributed.run"
     assert line["parity"]["planted_offsets_exact"] is True
     assert line["config"]["text_bytes_total"] == 2 * line["config"]["text_bytes_per_gpu"]
     assert line["config"]["matches"] > 500 and line["roofline"]["bound"] == "hbm"
+
+
+def test_bench_plain_launch_starts_its_own_ranks(ctx):
+    """`python bench.py --gpus 2 ...` launched PLAINLY, the way the driver launches the 1-GPU bench (no
+    torch.distributed.run, no WORLD_SIZE): the parent starts the two ranks itself before touching a GPU,
+    relays rank 0's JSON line and returns the worst rank's code."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--gib-per-gpu", "0.25", "--rehearse-on-one-gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # ONE JSON line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["launch"] == "self-launched ranks"
+    assert line["parity"]["planted_offsets_exact"] is True
+    assert line["config"]["text_bytes_total"] == 2 * line["config"]["text_bytes_per_gpu"]
+    # a rank that fails must fail the parent (and not hang it): an unknown workload makes argparse exit 2 in
+    # the parent itself, a bad variant fails inside the ranks
+    bad = subprocess.run(cmd + ["--variant", "12"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert bad.returncode != 0  # variant 12 (DMA only) is not part of the product library
 
 
 def test_bench_distributed_path_on_rccl_with_one_rank(ctx):

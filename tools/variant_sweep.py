@@ -11,6 +11,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("BMX_LIB", "exp")  # every slot of the kernel table: libbmx_exp.so (the product library refuses the others)
 
 import numpy as np
 import torch
