@@ -100,7 +100,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
         // what bmx_count_to_device publishes: a list that is not ordered yet counts as larger than any slot
         status[2] = needs_sort ? (total | (1ull << 62)) : total;
         status[3] = scan_err;
-        *count = 0;
+        count[0] = 0;
         bucket_overflow[0] = 0;
         bucket_overflow[1] = 0;
         // the host polls host_status[2] (pinned, fine-grained) for this search's sequence number

@@ -57,6 +57,11 @@ struct ScanArgs {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef volatile __attribute__((address_space(3))) uint32_t lds_u32; // explicit LDS accesses (ds_*), never flat_*
 typedef const __attribute__((address_space(1))) void gbl_void;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u32x4 lds_c128;
+typedef const __attribute__((address_space(3))) u32x2 lds_c64;
+typedef const __attribute__((address_space(3))) uint32_t lds_c32;
 
 __device__ __forceinline__ lds_void *to_lds(const void *p)
 {
@@ -102,13 +107,14 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint
     }
 }
 
-constexpr uint32_t QGRAM_TABLE = 4096; // entries of the 4-gram shift table (u32 in LDS: 16 KiB)
+constexpr uint32_t QGRAM_TABLE = 4096; // entries of the q-gram shift table (u8 in LDS: 4 KiB; built through a u32 copy in the tile area)
 
 struct LdsTables {
     const uint16_t *bad;  // 256 x u16 (entry of the pattern's last character: 0 if SKIP)
     const uint16_t *good; // m x u16
     const uint8_t *pat;   // m bytes
-    const uint32_t *qtab; // QGRAM_TABLE x u32, 4-gram walker only
+    const uint8_t *qtab;  // QGRAM_TABLE x u8, q-gram walkers only (shifts above 255 are stored as 255: a shorter shift is a safe one)
+    uint32_t bm[4];       // bitmap walker: bit c set iff character c occurs in the pattern (scalar copies)
     const uint8_t *bad8;  // 256 x u8 copy of bad[] (m <= 255): 64 LDS words = 2 per bank instead of 4
     lds_u32 *stage;       // the workgroup's parking buffer for the tile being walked: tile-local window starts
     lds_u32 *stage_cnt;   // running count of matches sent to this buffer (never reset: stage_seen is subtracted)
@@ -119,6 +125,8 @@ struct LdsTables {
     // scalar copies for the skip-loop walker
     uint32_t b_last, p3, g1, g2, g3;
     bool m4;
+    // quad-SAD skip loop: the pattern's last four / the four before them, as little-endian words
+    uint32_t sad_a, sad_b;
 };
 
 // A match found by a walker (called under divergence).  Appending to HBM costs a global atomic with
@@ -329,6 +337,102 @@ __device__ __forceinline__ void walk_lane_qgram(const ScanArgs &a, const LdsTabl
     }
 }
 
+// ---- 8-gram walker ---------------------------------------------------------------------------
+// The 4-gram table still leaves a quarter of the windows on DNA with a shift somewhere in 1..m-4 (61 of the
+// 256 possible 4-grams occur in a 64-byte pattern) and sends one window in 256 to the byte-wise verification:
+// the lanes of a wave drift apart, and with m = 64 more than half of all (wave, tile) pairs contain a
+// verification worth ~1300 cycles of dependent LDS reads, for which the whole workgroup waits at the tile
+// barrier (stamps, 4 GiB ACGT, m = 64: walk 30 %, barrier wait 39 % of a tile period).  The same rule on the
+// window's last EIGHT characters: hardly any 8-gram of the text occurs in the pattern (57 of 65,536 on DNA),
+// so practically every window shifts by the same m - 7, the lanes stay in step -- lockstep lanes also read
+// 32 different LDS banks, SEG being 4 x odd -- and a verification happens once per ~65,000 windows.  It starts
+// from the count of matching characters that the two words already in registers give (k = 0..8, no LDS).
+__device__ __forceinline__ uint32_t qgram8_hash(uint32_t w0, uint32_t w1) // w0 = text[i-7..i-4], w1 = text[i-3..i]
+{
+    return ((w0 * 0x9E3779B1u + w1) * 0x85EBCA77u) >> 20; // 12 bits
+}
+
+__device__ __forceinline__ void walk_lane_qgram8(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
+                                                 uint32_t hi, uint64_t tile_off)
+{
+    const uint32_t m = tb.m; // >= 8
+    uint32_t i = lo + m - 1;
+    const uint32_t ilim = hi + m - 1;
+    while (i < ilim) {
+        // text[i-7..i] out of the three aligned dwords that hold it (the third may reach 4 bytes past the window)
+        lds_c32 *p = (lds_c32 *)to_lds(T + ((i - 7) & ~3u));
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, (i - 7) & 3u);
+        const uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, (i - 7) & 3u);
+        const uint32_t s = tb.qtab[qgram8_hash(w0, w1)];
+        if (s != 0) {
+            i += s;
+            continue;
+        }
+        // kernel1.cl:20-22, the first eight comparisons from the registers: the last character is the top byte of w1
+        uint32_t k;
+        const uint32_t x1 = w1 ^ tb.sad_a;
+        if (x1 != 0) {
+            k = (uint32_t)__clz((int)x1) >> 3;
+        } else {
+            const uint32_t x0 = w0 ^ tb.sad_b;
+            k = x0 != 0 ? 4u + ((uint32_t)__clz((int)x0) >> 3) : 8u;
+        }
+        if (k == 8)
+            while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+        if (k == m) { // kernel1.cl:24
+            const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
+            report_hit(a, tb, astart, tile_off);
+            i += 1;
+            continue;
+        }
+        const int b = (int)tb.bad[w1 >> 24];
+        const int d1s = b - (int)k > 1 ? b - (int)k : 1;                   // kernel1.cl:28
+        const int d2s = (int)tb.good[k];                                    // kernel1.cl:29
+        i += (uint32_t)(k == 0 ? d1s : (d1s > d2s ? d1s : d2s));            // kernel1.cl:30-33
+    }
+}
+
+// ---- byte-wise walker behind a register bitmap -------------------------------------------------
+// walk_lane<false> pays two dependent LDS reads per window: the window's last character, then its shift.  On
+// a large alphabet most windows end in a character that does not occur in the pattern at all (printable text,
+// m = 16: 85 %) and the shift is simply m: a 128-bit set of the pattern's characters in four scalar registers
+// answers that with a handful of VALU instructions, and the table in LDS is only read for the other windows.
+// Same windows, same shifts as walk_lane<false>.
+__device__ __forceinline__ void walk_lane_bitmap(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
+                                                 uint32_t hi, uint64_t tile_off)
+{
+    const uint32_t m = tb.m;
+    uint32_t i = lo + m - 1;
+    const uint32_t ilim = hi + m - 1;
+    const uint32_t plast = tb.pat[m - 1];
+    const uint64_t set_lo = (uint64_t)tb.bm[0] | ((uint64_t)tb.bm[1] << 32), set_hi = (uint64_t)tb.bm[2] | ((uint64_t)tb.bm[3] << 32);
+    while (i < ilim) {
+        const uint32_t c = T[i];
+        const uint64_t set = (c & 64u) ? set_hi : set_lo;
+        if (c >= 128u || ((set >> (c & 63u)) & 1ull) == 0) { // not a character of the pattern: bad[c] == m (kernel1.cl:28,30)
+            i += m;
+            continue;
+        }
+        const uint32_t b = tb.bad[c];
+        if (c != plast) {
+            i += b;
+            continue;
+        }
+        uint32_t k = 1; // kernel1.cl:20-22
+        while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+        if (k == m) { // kernel1.cl:24
+            const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
+            report_hit(a, tb, astart, tile_off);
+            i += 1;
+            continue;
+        }
+        const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28
+        const int d2 = (int)tb.good[k];                             // kernel1.cl:29
+        i += (uint32_t)(d1 > d2 ? d1 : d2);                         // kernel1.cl:31
+    }
+}
+
 // ---- m = 1..3: compare every position, four at a time ---------------------------------------
 // With m <= 3 the shift tables cannot skip anything worth the two dependent LDS reads per window
 // (printable text, m = 2: 34 rounds per 68-byte segment).  The same windows are tested here from
@@ -442,6 +546,114 @@ __device__ __forceinline__ void walk_lane_spec(const ScanArgs &a, const LdsTable
     }
 }
 
+// ---- skip loop by quad-SAD: the walk without a dependency chain --------------------------------
+// The walkers above advance through a chain of dependent LDS reads (text byte -> shift -> next text
+// byte, ~100-150 cycles per link with 16 waves on the CU), and the workgroup waits at the tile barrier
+// for the lane with the smallest shifts: 42 % of a tile period at m = 16 on printable text
+// (DESIGN.md s5.3).  Classic fast Boyer-Moore implementations put a SKIP LOOP in front of the
+// match/shift step: run ahead to the next window whose END looks like the pattern's end, and only
+// there compare right to left and consult the tables.  This walker is that skip loop, vectorised:
+//   * a lane owns 80 consecutive filter positions of the tile and fetches them -- 88 bytes -- with
+//     five ds_read_b128 and one ds_read_b64, all independent (a lane stride of 16 x odd bytes keeps
+//     the 16-lane groups of ds_read_b128 on distinct banks);
+//   * v_mqsad_u32_u8 gives, per instruction, the masked sums of absolute differences of a 4-byte
+//     reference against the FOUR 4-byte windows at byte offsets 0..3 of a 64-bit operand: zero iff
+//     equal.  With the pattern's last four bytes as reference (F = 4), or its last eight in two
+//     chained instructions (F = 8, the sum accumulates), one or two instructions test four windows'
+//     ends; v_min3_u32 folds the results, so "no window of this lane ends like the pattern" --
+//     the usual case -- costs 3-4 VALU instructions per four windows and no LDS round trip;
+//   * a lane whose minimum is zero goes over its positions again, and at every window whose last F
+//     bytes equal the pattern's does what the reference does at a window (kernel1.cl:20-33): compare
+//     right to left, report on k == m and advance by 1, else advance by max(bad[T[i]] - k, 1) /
+//     good[k]; filter stops inside the advance are skipped (the shift is safe: nothing starts there).
+// The windows at which the reference's loop would find k < F are exactly the ones this loop never
+// stops at -- they cannot be matches -- so the match list is the same, by the same argument as for
+// any other order of visiting windows with safe shifts.  A reference byte of 0 is a wildcard for
+// the instruction (masked SAD): a pattern byte 0 only makes the filter wider.
+
+constexpr uint32_t SAD_SEG = 80; // filter positions (bytes) per lane: 16 x odd
+
+template <bool F8>
+__device__ __forceinline__ void verify_stops(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t sbeg,
+                                             uint32_t o, uint32_t lo_t, uint32_t hi_t, uint64_t tile_off, uint32_t ref_a,
+                                             uint32_t ref_b)
+{
+    const uint32_t m = tb.m;
+    uint32_t next_ok = lo_t; // first window start the reference's loop could visit next
+    for (uint32_t s = sbeg; s < sbeg + SAD_SEG; s += 4) {
+        lds_c32 *q = (lds_c32 *)to_lds(T + s);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        const u32x4 z = {0, 0, 0, 0};
+        u32x4 r;
+        if (F8) {
+            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d0 | ((uint64_t)d1 << 32), ref_b, z);
+            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d1 | ((uint64_t)d2 << 32), ref_a, r);
+        } else {
+            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d0 | ((uint64_t)d1 << 32), ref_a, z);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (r[j] != 0) continue;
+            const uint32_t p = s + j - o; // window start (wraps to a huge value for stops before the tile's first window)
+            if (p >= hi_t || p < next_ok) continue;
+            const uint32_t i = p + m - 1; // kernel1.cl:15: index of the window's last character
+            uint32_t k = 0;               // kernel1.cl:20-22
+            while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+            if (k == m) { // kernel1.cl:24
+                report_hit(a, tb, tile_off + (uint64_t)p, tile_off);
+                next_ok = p + 1;
+                continue;
+            }
+            const int b = (int)tb.bad[T[i]];
+            const int e1 = b - (int)k > 1 ? b - (int)k : 1;    // kernel1.cl:28
+            const int e2 = (int)tb.good[k];                     // kernel1.cl:29
+            next_ok = p + (uint32_t)(k == 0 ? e1 : (e1 > e2 ? e1 : e2)); // kernel1.cl:30-33
+        }
+    }
+}
+
+// lane_idx: 0 .. BLOCK-1.  [lo_t, hi_t): the tile's window starts to report (tile-local).
+template <bool F8>
+__device__ __forceinline__ void walk_lane_sad(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lane_idx,
+                                              uint32_t lo_t, uint32_t hi_t, uint64_t tile_off)
+{
+    constexpr uint32_t F = F8 ? 8 : 4;
+    const uint32_t m = tb.m;               // >= F
+    const uint32_t o = m - F;              // a window starting at p has its last F bytes at p + o
+    const uint32_t sbeg = (o & ~15u) + lane_idx * SAD_SEG; // this lane's first filter position: 16-byte aligned
+    // filter positions that belong to a window to report: [lo_t + o, hi_t + o)
+    if (sbeg >= hi_t + o || sbeg + SAD_SEG <= lo_t + o) return;
+    const uint32_t ref_a = tb.sad_a, ref_b = tb.sad_b; // pat[m-4..m), pat[m-8..m-4) as little-endian words
+    lds_c128 *q = (lds_c128 *)to_lds(T + sbeg);
+    uint32_t d[22];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const u32x4 v = q[c];
+        d[4 * c] = v.x, d[4 * c + 1] = v.y, d[4 * c + 2] = v.z, d[4 * c + 3] = v.w;
+    }
+    {
+        const u32x2 v = *(lds_c64 *)to_lds(T + sbeg + SAD_SEG); // the 4 (F = 4) or 7 (F = 8) bytes past the last position
+        d[20] = v.x, d[21] = v.y;
+    }
+    const u32x4 z = {0, 0, 0, 0};
+    uint32_t acc[4] = {~0u, ~0u, ~0u, ~0u}; // four short chains of v_min3_u32 (as asm: hipcc otherwise re-associates
+                                            // them into three instructions per four windows instead of two)
+#pragma unroll
+    for (int k = 0; k < 20; ++k) {
+        u32x4 r;
+        if (F8) {
+            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d[k] | ((uint64_t)d[k + 1] << 32), ref_b, z);
+            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d[k + 1] | ((uint64_t)d[k + 2] << 32), ref_a, r);
+        } else {
+            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d[k] | ((uint64_t)d[k + 1] << 32), ref_a, z);
+        }
+        asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[(2 * k) & 3]) : "v"(acc[(2 * k) & 3]), "v"(r.x), "v"(r.y));
+        asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[(2 * k + 1) & 3]) : "v"(acc[(2 * k + 1) & 3]), "v"(r.z), "v"(r.w));
+    }
+    if (min(min(acc[0], acc[1]), min(acc[2], acc[3])) != 0) return; // no window of this lane's ends like the pattern
+    verify_stops<F8>(a, tb, T, sbeg, o, lo_t, hi_t, tile_off, ref_a, ref_b);
+}
+
 // wait until at most n of this wave's vector-memory operations are outstanding
 __device__ __forceinline__ void wait_vmcnt_at_most(uint32_t n)
 {
@@ -464,8 +676,11 @@ __device__ __forceinline__ void wait_vmcnt_at_most(uint32_t n)
 // >= 0x80 cannot occur in an ASCII pattern: their entry is the full shift m.  The scalars
 // are forced through readfirstlane HERE: a load still pending when the walk first uses it
 // would cost an s_waitcnt vmcnt(0) that also drains the LDS-DMA in flight.
-template <bool SKIP, bool QGRAM = false>
-__device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *base, uint32_t tid, uint32_t nthreads)
+// Q = 4 / 8: also build the q-gram shift table of walk_lane_qgram / walk_lane_qgram8.  `scratch` is LDS that is
+// free until the first tile arrives (the tile buffers), at least 4 * QGRAM_TABLE bytes.
+template <bool SKIP, int Q = 0>
+__device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *base, uint32_t tid, uint32_t nthreads,
+                                                 uint8_t *scratch = nullptr)
 {
     const uint32_t m = a.m;
     uint16_t *s_bad = reinterpret_cast<uint16_t *>(base);
@@ -493,15 +708,31 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
     tb.bad8 = s_bad8;
     uint8_t *end = s_bad8 + 256;
     tb.qtab = nullptr;
-    if (QGRAM) { // every thread of the workgroup is here (two barriers)
-        uint32_t *s_q = reinterpret_cast<uint32_t *>(s_bad8 + 256);
-        for (uint32_t i = tid; i < QGRAM_TABLE; i += nthreads) s_q[i] = m - 3;
+    if (Q != 0) { // every thread of the workgroup is here (three barriers)
+        // right-most end position wins = the minimum of m-1-j per hash: atomicMin needs words, the walkers want the
+        // table small (4 KiB leave room for 76 KiB tiles): built as u32 in the tile area, stored as u8
+        uint32_t *s_q = reinterpret_cast<uint32_t *>(scratch);
+        for (uint32_t i = tid; i < QGRAM_TABLE; i += nthreads) s_q[i] = m - (Q - 1);
         __syncthreads();
-        for (uint32_t j = 3 + tid; j < m; j += nthreads) // right-most end position wins: the minimum of m-1-j
-            atomicMin(&s_q[qgram_hash(a.tab.pat[j - 3], a.tab.pat[j - 2], a.tab.pat[j - 1], a.tab.pat[j])], m - 1 - j);
+        for (uint32_t j = Q - 1 + tid; j < m; j += nthreads) {
+            uint32_t h;
+            if (Q == 4) {
+                h = qgram_hash(a.tab.pat[j - 3], a.tab.pat[j - 2], a.tab.pat[j - 1], a.tab.pat[j]);
+            } else {
+                const uint32_t w0 = (uint32_t)a.tab.pat[j - 7] | ((uint32_t)a.tab.pat[j - 6] << 8) |
+                                    ((uint32_t)a.tab.pat[j - 5] << 16) | ((uint32_t)a.tab.pat[j - 4] << 24);
+                const uint32_t w1 = (uint32_t)a.tab.pat[j - 3] | ((uint32_t)a.tab.pat[j - 2] << 8) |
+                                    ((uint32_t)a.tab.pat[j - 1] << 16) | ((uint32_t)a.tab.pat[j] << 24);
+                h = qgram8_hash(w0, w1);
+            }
+            atomicMin(&s_q[h], m - 1 - j);
+        }
         __syncthreads();
-        tb.qtab = s_q;
-        end = reinterpret_cast<uint8_t *>(s_q + QGRAM_TABLE);
+        uint8_t *s_q8 = s_bad8 + 256;
+        for (uint32_t i = tid; i < QGRAM_TABLE; i += nthreads) s_q8[i] = (uint8_t)(s_q[i] < 255u ? s_q[i] : 255u);
+        __syncthreads(); // the scratch area is the first tile's buffer: nobody fetches into it before everybody has read it
+        tb.qtab = s_q8;
+        end = s_q8 + QGRAM_TABLE;
     }
     // parking area for matches: [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
     tb.stage_cap = a.stage_cap;
@@ -518,6 +749,26 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
     tb.m = m;
     tb.m4 = m >= 4;
     tb.b_last = tb.p3 = tb.g1 = tb.g2 = tb.g3 = 0;
+    tb.sad_a = tb.sad_b = 0;
+    {   // the pattern's characters as a 128-bit set (walk_lane_bitmap): every lane ORs its share, the wave reduces
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t i = (tid & 63u); i < m; i += 64) {
+            const uint32_t c = a.tab.pat[i] & 127u;
+            w[c >> 5] |= 1u << (c & 31u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) w[q] |= __shfl_xor(w[q], d);
+            tb.bm[q] = __builtin_amdgcn_readfirstlane(w[q]);
+        }
+    }
+    if (m >= 4)
+        tb.sad_a = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 4] | ((uint32_t)a.tab.pat[m - 3] << 8) |
+                                                  ((uint32_t)a.tab.pat[m - 2] << 16) | ((uint32_t)a.tab.pat[m - 1] << 24));
+    if (m >= 8)
+        tb.sad_b = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 8] | ((uint32_t)a.tab.pat[m - 7] << 8) |
+                                                  ((uint32_t)a.tab.pat[m - 6] << 16) | ((uint32_t)a.tab.pat[m - 5] << 24));
     if (SKIP) {
         tb.b_last = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.bad[last_char & 127]);
         if (tb.m4) {

@@ -40,6 +40,10 @@ namespace bmx {
 // walker (bmx_scan_common.h), needs m >= 4 and 16 KiB more LDS.  WALK 4: byte-wise walker with two
 // windows in flight.  WALK 6: m = 1..3, every position compared from aligned dwords (the workgroup-tile
 // kernels' walker for short patterns).
+// WALK 7 / 8: skip loop by quad-SAD on the pattern's last 4 (m >= 4) / 8 (m >= 8) bytes, match and shift by the
+// reference's rule at every stop (walk_lane_sad, bmx_scan_common.h): no dependent LDS chain.
+// WALK 9: byte-wise walker behind a 128-bit set of the pattern's characters in scalar registers (the shift table in
+// LDS is only read for windows that end in a character of the pattern).  WALK 10: 8-gram walker, m >= 8.
 // (A WALK 1 that fetched the last four characters with one unaligned ds_read_b32 was
 // 35 % slower -- unaligned LDS dwords -- and is gone)
 // LOADERS: 0 = every wave issues its share of the tile DMA and then walks.
@@ -49,14 +53,35 @@ namespace bmx {
 // wave has started its walk (a wave's own DMA instructions must be accepted first),
 // and the waves released last make everybody wait at the barrier (~1500 cycles).
 // A dedicated loader wave takes both off the walkers' critical path.
-template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0, int LOADERS = 0>
+// SEGI (with LOADERS != 0): the loader waves also walk, SEGI window starts per lane (a shorter share than the
+// other waves' SEG, so that "issue, then walk a little" and "walk a lot" end together); LOADERS < 0: the LAST
+// |LOADERS| waves (the youngest) are the loaders instead of the first.
+// GRADE != 0 (16 waves, LOADERS 0): the four groups of four waves walk shares of different length -- the group that
+// gets its DMA instructions accepted first (the oldest waves) the longest, the last one the shortest -- with the same
+// tile size 64 * 4 * (sum of the four) as the uniform SEG.  grade_seg(GRADE, g): window starts per lane of group g.
+__host__ __device__ constexpr int grade_seg(int grade, int g, int seg)
+{
+    return grade == 1 ? (g == 0 ? 108 : g == 1 ? 92 : g == 2 ? 60 : 44)
+         : grade == 2 ? (g == 0 ? 100 : g == 1 ? 84 : g == 2 ? 68 : 52)
+         : grade == 3 ? (g == 0 ? 92 : g == 1 ? 84 : g == 2 ? 68 : 60)
+         : grade == 4 ? (g == 0 ? 44 : g == 1 ? 60 : g == 2 ? 92 : 108) // the other way round (control)
+                      : seg;
+}
+
+template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0, int LOADERS = 0, int SEGI = 0, int GRADE = 0>
 __device__ __forceinline__ void scan_body(const ScanArgs &a)
 {
+    static_assert(GRADE == 0 || (BLOCK == 1024 && LOADERS == 0 && WALK != 7 && WALK != 8), "");
+    static_assert(GRADE == 0 || grade_seg(GRADE, 0, 0) + grade_seg(GRADE, 1, 0) + grade_seg(GRADE, 2, 0) + grade_seg(GRADE, 3, 0) == 4 * SEG,
+                  "a graded split keeps the tile size");
     static_assert(SEG % 4 == 0 && (SEG / 4) % 2 == 1, "SEG must be 4 * odd (LDS bank spread)");
     static_assert(BLOCK % 64 == 0, "whole waves");
-    static_assert(LOADERS >= 0 && LOADERS * 64 < BLOCK, "");
-    constexpr uint32_t WALKERS = BLOCK - 64 * LOADERS; // lanes that walk
-    constexpr uint32_t TILE = WALKERS * SEG;
+    constexpr int NL = LOADERS < 0 ? -LOADERS : LOADERS; // loader waves
+    constexpr bool YOUNG = LOADERS < 0;                   // ... are the workgroup's last waves
+    constexpr int NW = BLOCK / 64;
+    static_assert(NL * 64 < BLOCK, "");
+    static_assert(SEGI == 0 || (NL > 0 && SEGI % 4 == 0 && (SEGI / 4) % 2 == 1), "SEGI must be 4 * odd");
+    constexpr uint32_t TILE = 64u * (uint32_t)(NL * SEGI + (NW - NL) * SEG);
     static_assert(TILE % 16 == 0, "tiles start on 16-B chunks");
 
     extern __shared__ uint4 smem_u4[];
@@ -67,25 +92,51 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lane = tid & 63;
-    LdsTables tb = load_tables<WALK == 2, WALK == 3>(a, smem + 2 * buf_bytes, tid, BLOCK);
+    const bool is_loader = NL > 0 && (YOUNG ? wave >= (uint32_t)(NW - NL) : wave < (uint32_t)NL); // wave-uniform
+    const uint32_t iwave = YOUNG ? wave - (uint32_t)(NW - NL) : wave; // index among the loaders (meaningless otherwise)
+    LdsTables tb = load_tables<WALK == 2, WALK == 3 ? 4 : (WALK == 10 ? 8 : 0)>(a, smem + 2 * buf_bytes, tid, BLOCK, smem);
 
     const uint32_t nchunk = buf_bytes >> 4; // 16-B chunks per tile incl. halo
+    // PRIO: the waves that are still issuing their share of the DMA outrank the ones that already walk (the
+    // VALU-dense skip loop of older waves otherwise starves the address arithmetic of the younger ones).
+    constexpr bool PRIO = WALK == 7 || WALK == 8 || MODE == 7;
     auto issue_tile = [&](uint64_t t, uint8_t *dst) {
         const uint64_t tile_off = t * (uint64_t)TILE;
         const uint8_t *gsrc = a.text16 + tile_off;
         // issuing wave w takes chunks [64w, 64w+64), then strides by the number of issuing lanes
-        constexpr uint32_t ISSUERS = LOADERS ? 64 * LOADERS : BLOCK;
-        for (uint32_t c0 = wave * 64; c0 < nchunk; c0 += ISSUERS) {
-            const uint32_t c = c0 + lane;
-            const uint64_t goff = tile_off + ((uint64_t)c << 4);
-            if (c < nchunk && goff < a.data_end) dma16<AUX>(gsrc + ((uint64_t)c << 4), dst + ((uint64_t)c0 << 4));
+        constexpr uint32_t ISSUERS = NL ? 64 * NL : BLOCK;
+        const uint32_t first = (NL ? iwave : wave) * 64;
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
+        if (tile_off + buf_bytes <= a.data_end) {
+            // the whole tile and its halo lie inside the text (every tile but the last one or two): no per-lane
+            // bounds, a scalar base plus a 32-bit lane offset per instruction
+            const uint32_t lane16 = lane << 4;
+            uint32_t c0 = first;
+            for (; c0 + 64 <= nchunk; c0 += ISSUERS) dma16<AUX>(gsrc + ((uint64_t)c0 << 4) + lane16, dst + ((uint64_t)c0 << 4));
+            if (c0 < nchunk && c0 + lane < nchunk) dma16<AUX>(gsrc + ((uint64_t)c0 << 4) + lane16, dst + ((uint64_t)c0 << 4));
+        } else {
+            for (uint32_t c0 = first; c0 < nchunk; c0 += ISSUERS) {
+                const uint32_t c = c0 + lane;
+                const uint64_t goff = tile_off + ((uint64_t)c << 4);
+                if (c < nchunk && goff < a.data_end) dma16<AUX>(gsrc + ((uint64_t)c << 4), dst + ((uint64_t)c0 << 4));
+            }
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
-    const bool is_loader = LOADERS > 0 && wave < (uint32_t)LOADERS; // wave-uniform
-    const bool issues = LOADERS == 0 || is_loader;
-    const uint32_t wtid = tid - 64 * LOADERS; // walker lane index (meaningless for loaders)
-    uint64_t t = a.tile_begin + blockIdx.x;
+    const bool issues = NL == 0 || is_loader;
+    // this lane's window starts within a tile: loaders' shares first, then the other waves'
+    uint32_t seg_lo = is_loader ? (iwave * 64 + lane) * (uint32_t)SEGI
+                                : 64u * NL * SEGI + ((YOUNG ? wave : wave - NL) * 64 + lane) * (uint32_t)SEG;
+    uint32_t seg_len = is_loader ? (uint32_t)SEGI : (uint32_t)SEG;
+    if (GRADE != 0) { // wave-uniform
+        const uint32_t g = wave >> 2;
+        const uint32_t s0 = grade_seg(GRADE, 0, SEG), s1 = grade_seg(GRADE, 1, SEG), s2 = grade_seg(GRADE, 2, SEG), s3 = grade_seg(GRADE, 3, SEG);
+        seg_len = g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
+        const uint32_t before = g == 0 ? 0u : g == 1 ? s0 : g == 2 ? s0 + s1 : s0 + s1 + s2; // per lane of a four-wave group
+        seg_lo = 256u * before + ((wave & 3u) * 64 + lane) * seg_len;
+    }
+    uint64_t t = a.tile_begin + blockIdx.x, t_prev = 0;
     uint32_t it = 0; // tiles walked so far by this workgroup
     uint32_t seen[2] = {0, 0}; // the parking buffers' counts as of their last collection
     auto park_buf = [&](uint32_t p) { return tb.stage_area + p * tb.stage_cap; };
@@ -104,8 +155,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         return v;
     };
     st_prev = stamp();
+    const unsigned long long st_t0 = MODE == 8 ? __builtin_amdgcn_s_memtime() : st_prev; // MODE 8: the two clock stamps only
+    const unsigned long long st_r0 = MODE == 5 || MODE == 8 ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-    for (; t < a.tile_end; t += gridDim.x) {
+    for (uint64_t t_next = 0; t < a.tile_end; t_prev = t, t = t_next) {
         // (A) this tile's DMA has landed for every wave, and every wave has
         //     finished walking the other buffer, which is refilled next.
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
@@ -161,8 +214,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         const uint64_t tile_off = t * (uint64_t)TILE;
 
         // this lane's window starts, tile-local: [lo, hi)
-        uint32_t lo = wtid * SEG;
-        uint32_t hi = lo + SEG;
+        uint32_t lo = seg_lo;
+        uint32_t hi = lo + seg_len;
         if (tile_off < a.first) {
             const uint32_t f = (uint32_t)(a.first - tile_off);
             lo = lo > f ? lo : f;
@@ -170,9 +223,19 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         const uint64_t rem = a.own_end - tile_off; // > 0 because t < tile_end
         if (rem < (uint64_t)hi) hi = (uint32_t)rem;
 
-        if (MODE != 1 && !is_loader && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi) {
+        if constexpr (WALK == 7 || WALK == 8) { // quad-SAD skip loop: lanes own filter positions, not window starts
+            static_assert(LOADERS == 0, "");
+            static_assert((uint32_t)BLOCK * SAD_SEG >= TILE + 16, "the lanes' filter positions must cover a tile");
+            const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
+            const uint32_t hi_t = rem < (uint64_t)TILE ? (uint32_t)rem : TILE;
+            if (MODE != 1) walk_lane_sad<WALK == 8>(a, tb, T, tid, lo_t, hi_t, tile_off);
+        } else if (MODE != 1 && (!is_loader || SEGI > 0) && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi) {
             if constexpr (WALK == 3)
                 walk_lane_qgram(a, tb, T, lo, hi, tile_off);
+            else if constexpr (WALK == 10)
+                walk_lane_qgram8(a, tb, T, lo, hi, tile_off);
+            else if constexpr (WALK == 9)
+                walk_lane_bitmap(a, tb, T, lo, hi, tile_off);
             else if constexpr (WALK == 4)
                 walk_lane_spec(a, tb, T, lo, hi, tile_off);
             else if constexpr (WALK == 5)
@@ -184,7 +247,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         }
         if (issue_now && issue_late) issue_tile(tn, cur ? buf0 : buf1);
         if (prev_n != 0) // the previous tile's matches: reserved before this tile's DMA, stored now
-            finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
+            finish_parked<BLOCK>(a, tb, t_prev * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
         ++it;
         if (MODE == 5) {
             const unsigned long long x = stamp();
@@ -193,6 +256,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             ++st_n;
         }
         cur ^= 1;
+        t_next = tn;
     }
     if (MODE != 1 && tb.stage_cap != 0 && it != 0) { // what the last tile left parked
         __builtin_amdgcn_s_waitcnt(0);
@@ -203,23 +267,25 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         if (prev_n != 0) {
             unsigned long long reserved = 0;
             if (tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
-            finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
+            finish_parked<BLOCK>(a, tb, t_prev * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
         }
     }
-    if (MODE == 5 && a.stamps != nullptr && lane == 0) {
+    if ((MODE == 5 || MODE == 8) && a.stamps != nullptr && lane == 0) {
         unsigned long long *o = a.stamps + ((uint64_t)blockIdx.x * (BLOCK / 64) + wave) * 8;
         o[0] = st_issue;
         o[1] = st_walk;
         o[2] = st_dma;
         o[3] = st_bar;
         o[4] = st_n;
+        o[5] = __builtin_amdgcn_s_memtime() - st_t0;     // shader cycles over the loop
+        o[6] = __builtin_amdgcn_s_memrealtime() - st_r0; // 100 MHz ticks over the same span: clock = o[5] / o[6] x 100 MHz
     }
 }
 
-template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0, int LOADERS = 0>
+template <int BLOCK, int SEG, int AUX = 0, int MODE = 0, int WALK = 0, int LOADERS = 0, int SEGI = 0, int GRADE = 0>
 __global__ __launch_bounds__(BLOCK) void scan_kernel(const ScanArgs a)
 {
-    scan_body<BLOCK, SEG, AUX, MODE, WALK, LOADERS>(a);
+    scan_body<BLOCK, SEG, AUX, MODE, WALK, LOADERS, SEGI, GRADE>(a);
 }
 
 // The same kernel for geometries that put 32 waves on a CU (two workgroups of 16): measured on MI355X, a

@@ -33,11 +33,11 @@
 namespace bmx {
 
 // BLOCK threads, SEG window starts per lane (4 * odd), AUX DMA cache policy,
-// SKIP walker choice, MODE 0 product / 5 stamps (diagnostic).
+// WALK 0 byte-wise / 2 skip loop / 10 8-gram walker, MODE 0 product / 1 DMA only / 5 stamps (diagnostic).
 // PRIO 1: static s_setprio by wave age.  With 4 waves per SIMD the younger waves lose
 // the issue arbitration (stamps: waves 12-15 walk 20 % longer than waves 0-3) and the
 // whole workgroup waits for them at the barrier; PRIO 1 gives waves 4k..4k+3 priority k.
-template <int BLOCK, int SEG, int AUX, bool SKIP, int MODE, int PRIO = 0>
+template <int BLOCK, int SEG, int AUX, int WALK, int MODE, int PRIO = 0>
 __global__ __launch_bounds__(BLOCK) void scan_ring_kernel(const ScanArgs a_in)
 {
     static_assert(SEG % 4 == 0 && (SEG / 4) % 2 == 1, "SEG must be 4 * odd (LDS bank spread)");
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(BLOCK) void scan_ring_kernel(const ScanArgs a_in)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t lane = tid & 63;
 
-    const LdsTables tb = load_tables<SKIP>(a, smem + 3ull * buf_bytes, tid, BLOCK);
+    const LdsTables tb = load_tables<WALK == 2, WALK == 10 ? 8 : 0>(a, smem + 3ull * buf_bytes, tid, BLOCK, smem);
     __syncthreads();
 
     // DMA of one tile: ninstr wave-instructions of 1 KiB, instruction j issued by wave j % WAVES.
@@ -124,7 +124,12 @@ __global__ __launch_bounds__(BLOCK) void scan_ring_kernel(const ScanArgs a_in)
         }
         const uint64_t rem = a.own_end - tile_off; // > 0 because t < tile_end
         if (rem < (uint64_t)hi) hi = (uint32_t)rem;
-        if (lo < hi) walk_lane<SKIP>(a, tb, T, lo, hi, tile_off);
+        if (MODE != 1 && lo < hi) { // (MODE 1: DMA only, a timing experiment)
+            if constexpr (WALK == 10)
+                walk_lane_qgram8(a, tb, T, lo, hi, tile_off);
+            else
+                walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
+        }
         if (MODE == 5) {
             const unsigned long long x = stamp();
             st_walk += x - st_prev;

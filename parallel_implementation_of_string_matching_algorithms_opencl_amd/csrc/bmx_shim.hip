@@ -66,9 +66,12 @@ struct Variant {
     int block;
     int seg;
     int nbuf;
-    int loaders; // kind 0: waves that only issue DMA
+    int loaders; // kind 0: waves that issue all of the DMA (< 0: the last ones); they walk `segi` window starts per lane (0: none)
+    int segi;
     bool stamps; // diagnostic build that writes s_memtime sums (bmx_scan_stamps)
-    bool qgram;  // 4-gram walker: shift table in LDS, needs the canonical shift tables
+    bool qgram;  // 4-gram walker: shift table in LDS
+    int canon_minm; // > 0: the walker skips with a filter of its own (4-gram table, quad-SAD) and therefore needs the
+                    // canonical shift tables and a pattern of at least this length; 0: any tables, any m
     void (*kernel)(const bmx::ScanArgs); // nullptr: this slot is not built into this library
     void (*kernel_short)(const bmx::ScanArgs);
 };
@@ -80,22 +83,26 @@ struct Variant {
 // only in libbmx_exp.so, the same sources compiled with -DBMX_EXPERIMENTS for tools/ (BMX_LIB=exp).
 // bmx_set_variant() refuses a slot that is not built: no caller of the shipped C ABI can select a kernel
 // that returns a wrong match list (tests/test_gpu_parity.py::test_product_library_accepts_only_its_variants).
-#define BMX_ABSENT {0, 0, 0, 0, 0, false, false, nullptr, nullptr}
+#define BMX_ABSENT {0, 0, 0, 0, 0, 0, false, false, 0, nullptr, nullptr}
 #ifdef BMX_EXPERIMENTS
 #define BMX_EXP(...) __VA_ARGS__
 #else
 #define BMX_EXP(...) BMX_ABSENT
 #endif
 #define BMX_TILE(B, S, AUX, MODE, W) BMX_TILE_L(B, S, AUX, MODE, W, 0)
-#define BMX_TILE_L(B, S, AUX, MODE, W, L) \
-    {0, B, S, 2, L, (MODE) == 5, (W) == 3, bmx::scan_kernel<B, S, AUX, MODE, W, L>, bmx::scan_kernel<B, S, AUX, MODE, 6, L>}
+#define BMX_TILE_L(B, S, AUX, MODE, W, L) BMX_TILE_LS(B, S, AUX, MODE, W, L, 0)
+#define BMX_TILE_LS(B, S, AUX, MODE, W, L, SI) BMX_TILE_G(B, S, AUX, MODE, W, L, SI, 0)
+#define BMX_TILE_G(B, S, AUX, MODE, W, L, SI, G) \
+    {0, B, S, 2, L, SI, (MODE) == 5 || (MODE) == 8, (W) == 3 || (W) == 10, \
+     (W) == 3 || (W) == 7 || (W) == 9 ? 4 : ((W) == 8 || (W) == 10 ? 8 : 0), \
+     bmx::scan_kernel<B, S, AUX, MODE, W, L, SI, G>, bmx::scan_kernel<B, S, AUX, MODE, 6, L, SI, G>}
 #define BMX_TILE_W32(B, S, AUX, MODE, W) /* 32 waves per CU: the 80-SGPR build */ \
-    {0, B, S, 2, 0, (MODE) == 5, (W) == 3, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, MODE, 6, 0>}
-#define BMX_RING(B, S, AUX, SKIP, MODE) BMX_RING_P(B, S, AUX, SKIP, MODE, 0)
-#define BMX_RING_P(B, S, AUX, SKIP, MODE, P) \
-    {2, B, S, 3, 0, (MODE) == 5, false, bmx::scan_ring_kernel<B, S, AUX, SKIP, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, false, MODE, P>}
+    {0, B, S, 2, 0, 0, (MODE) == 5, (W) == 3, (W) == 3 ? 4 : 0, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, MODE, 6, 0>}
+#define BMX_RING(B, S, AUX, SKIP, MODE) BMX_RING_P(B, S, AUX, (SKIP) ? 2 : 0, MODE, 0)
+#define BMX_RING_P(B, S, AUX, W, MODE, P) \
+    {2, B, S, 3, 0, 0, (MODE) == 5, (W) == 10, (W) == 10 ? 8 : 0, bmx::scan_ring_kernel<B, S, AUX, W, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, 0, MODE, P>}
 #define BMX_WAVE(WV, S, AUX, MODE, D, NB)                                                      \
-    {1, (WV) * 64, S, NB, 0, false, false, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>}
+    {1, (WV) * 64, S, NB, 0, 0, false, false, 0, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>}
 const Variant g_variants[] = {
     BMX_TILE(1024, 68, 2, 0, 0),                 // 0: PRODUCT -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
                                                  //    (the automatic choice for m < 4 and for dense small-alphabet results)
@@ -133,6 +140,45 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE(1024, 68, 2, 6, 0)),        // 28: default kernel, half of the waves issue their DMA share AFTER their walk
     BMX_TILE(1024, 76, 2, 0, 0),                 // 29: PRODUCT -- 76 KiB tiles, room for 512 parked matches only (picked
                                                  //     automatically for patterns over more than 8 distinct symbols, m >= 4)
+    BMX_EXP(BMX_TILE(1024, 76, 2, 0, 7)),        // 30: 76 KiB tiles, quad-SAD skip loop on the last 4 pattern bytes (valid lists; slower: DESIGN.md s5.4)
+    BMX_EXP(BMX_TILE(1024, 76, 2, 0, 8)),        // 31: the same on the last 8 pattern bytes (m >= 8)
+    BMX_EXP(BMX_TILE(1024, 76, 2, 1, 0)),        // 32: DMA only, 76 KiB tiles (timing; no valid match list)
+    BMX_EXP(BMX_TILE(1024, 76, 2, 5, 7)),        // 33: stamps, quad-SAD skip loop (last 4)
+    BMX_EXP(BMX_TILE(1024, 76, 2, 5, 0)),        // 34: stamps, 76 KiB tiles, byte-wise walker
+    BMX_EXP(BMX_TILE(1024, 76, 2, 5, 8)),        // 35: stamps, quad-SAD skip loop (last 8)
+    BMX_EXP(BMX_TILE(1024, 76, 2, 7, 0)),        // 36: variant 29 with s_setprio 3 around the DMA issue
+    BMX_EXP(BMX_TILE(1024, 76, 2, 8, 0)),        // 37: variant 29 + two clock stamps around the loop (in-kernel clock)
+    BMX_EXP(BMX_TILE(1024, 76, 2, 8, 7)),        // 38: variant 30 + clock stamps
+    BMX_EXP(BMX_TILE(1024, 76, 2, 8, 8)),        // 39: variant 31 + clock stamps
+    // split roles: |L| waves issue all of the DMA and walk a short share, the others only walk, a long one
+    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 0, 0, 8, 52)),   // 40: first 8 waves issue and walk 52 B/lane, last 8 walk 100
+    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 0, 0, -8, 52)),  // 41: the LAST 8 waves issue
+    BMX_EXP(BMX_TILE_LS(1024, 92, 2, 0, 0, 8, 60)),    // 42
+    BMX_EXP(BMX_TILE_LS(1024, 108, 2, 0, 0, 8, 44)),   // 43
+    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 7, 0, 8, 52)),   // 44: 40 with s_setprio 3 around the issue
+    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 7, 0, -8, 52)),  // 45: 41 with s_setprio
+    BMX_EXP(BMX_TILE_LS(1024, 92, 2, 0, 0, 4, 28)),    // 46: 4 issuers
+    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 0, 0, 12, 68)),  // 47: 12 issuers walk 68, 4 walk 100
+    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 5, 0, 8, 52)),   // 48: stamps of 40
+    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 5, 0, -8, 52)),  // 49: stamps of 41
+    BMX_EXP(BMX_TILE(1024, 68, 2, 5, 3)),              // 50: stamps of 24 (4-gram walker)
+    BMX_EXP(BMX_TILE(1024, 68, 2, 8, 3)),              // 51: clock stamps of 24
+    BMX_EXP(BMX_TILE(1024, 76, 2, 0, 9)),              // 52: 76 KiB tiles, byte-wise walker behind the register bitmap (valid lists; slower)
+    BMX_TILE(1024, 76, 2, 0, 10),                      // 53: PRODUCT -- 76 KiB tiles, 8-gram walker (m >= 8)
+    BMX_TILE(1024, 76, 2, 0, 3),                       // 54: PRODUCT -- 76 KiB tiles, 4-gram walker
+    BMX_EXP(BMX_TILE(1024, 76, 2, 5, 9)),              // 55: stamps of 52
+    BMX_EXP(BMX_TILE(1024, 76, 2, 5, 10)),             // 56: stamps of 53
+    BMX_EXP(BMX_RING_P(1024, 52, 2, 0, 1, 0)),         // 57: ring, DMA only, 3 x 52 KiB
+    BMX_EXP(BMX_RING_P(1024, 44, 2, 0, 1, 0)),         // 58: ring, DMA only, 3 x 44 KiB
+    BMX_EXP(BMX_RING_P(1024, 44, 2, 10, 0, 0)),        // 59: ring, 8-gram walker, 3 x 44 KiB
+    BMX_EXP(BMX_RING_P(1024, 44, 2, 0, 0, 0)),         // 60: ring, byte-wise walker, 3 x 44 KiB
+    BMX_EXP(BMX_RING_P(1024, 36, 2, 0, 1, 0)),         // 61: ring, DMA only, 3 x 36 KiB
+    BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 0, 0, 0, 1)),   // 62: variant 29, shares graded 108 / 92 / 60 / 44 by wave age
+    BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 0, 0, 0, 2)),   // 63: 100 / 84 / 68 / 52
+    BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 0, 0, 0, 3)),   // 64: 92 / 84 / 68 / 60
+    BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 0, 0, 0, 4)),   // 65: 44 / 60 / 92 / 108 (control: the wrong way round)
+    BMX_EXP(BMX_TILE_G(1024, 76, 2, 5, 0, 0, 0, 1)),   // 66: stamps of 62
+    BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 10, 0, 0, 2)),  // 67: 8-gram walker, graded 100 / 84 / 68 / 52
 };
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
@@ -179,7 +225,8 @@ namespace {
 
 uint64_t unit_bytes(const Variant &v)
 {
-    return v.kind != 1 ? (uint64_t)(v.block - 64 * v.loaders) * v.seg : 64ull * v.seg;
+    const int nl = v.loaders < 0 ? -v.loaders : v.loaders;
+    return v.kind != 1 ? 64ull * (uint64_t)(nl * v.segi + (v.block / 64 - nl) * v.seg) : 64ull * v.seg;
 }
 
 // LDS of one workgroup with two buffers of `cap` parked matches (bmx_scan_common.h report_hit).
@@ -188,7 +235,7 @@ uint32_t lds_bytes_with(const Variant &v, int32_t m, uint32_t cap)
     const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
     const uint32_t waves = (uint32_t)v.block / 64u;
     const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u) + 256 +
-                            (v.qgram ? bmx::QGRAM_TABLE * 4u : 0u) + (cap ? 2u * cap * 4u + 32u : 0u);
+                            (v.qgram ? bmx::QGRAM_TABLE : 0u) + (cap ? 2u * cap * 4u + 32u : 0u);
     if (v.kind != 1) return (uint32_t)v.nbuf * ((uint32_t)unit_bytes(v) + halo16) + tables;
     return waves * v.nbuf * (64u * v.seg + halo16) + tables;
 }
@@ -218,26 +265,27 @@ int blocks_per_cu_for(const bmx_ctx *ctx, const Variant &v, int32_t m)
     return b;
 }
 
-// Default kernel choice.  On small alphabets (DNA: 4 symbols) almost every window ends in
-// a character of the pattern and the reference's one-character bad-symbol rule shifts by a few
-// bytes: the walkers, not HBM, bound the scan (4 GiB ACGT, m = 64: 1.2 TB/s byte-wise walker,
-// 2.0 skip loop, 2.3 skip loop + two workgroups per CU = variant 2).  The 4-gram walker
-// (walk_lane_qgram: the same rule on the window's last four characters) shifts by ~50 and
-// reaches 5.7 TB/s on the default geometry; it needs the canonical shift tables (below).
+// Default kernel choice.  On small alphabets (DNA: 4 symbols) almost every window ends in a character of the
+// pattern and the reference's one-character bad-symbol rule shifts by a few bytes: the walkers, not HBM, bound
+// the scan (4 GiB ACGT, m = 64: 1.2 TB/s byte-wise walker, 2.0 skip loop, 2.3 skip loop + two workgroups per
+// CU = variant 2).  The q-gram walkers apply the same rule to the window's last four / eight characters
+// (walk_lane_qgram, walk_lane_qgram8): 5.7 TB/s with four, 6.4 with eight (whose lanes stay in step: hardly any
+// 8-gram of the text occurs in the pattern); they need the canonical shift tables (below).
 uint32_t lds_bytes_for(const Variant &v, int32_t m);
 
-constexpr int VARIANT_QGRAM = 24;
+constexpr int VARIANT_QGRAM4 = 54;   // 4-gram walker, 76 KiB tiles
+constexpr int VARIANT_QGRAM8 = 53;   // 8-gram walker, 76 KiB tiles
 constexpr int VARIANT_BIG_TILE = 29; // 76 KiB tiles: +2 % on large alphabets, but room for 512 parked matches per tile only
 
 // `canonical`: the shift tables in use are the ones bmx_build_tables makes (always so when the caller
-// passes none).  The 4-gram walker skips with its own table and only leaves a verified window with
+// passes none).  The q-gram walkers skip with a table of their own and only leave a verified window with
 // the caller's shifts, so with tables that shift FURTHER than the canonical ones (unsafe ones: the
-// reference kernel would miss matches) it would not reproduce the reference kernel's list.
+// reference kernel would miss matches) they would not reproduce the reference kernel's list.
 int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical)
 {
     if (!ctx->auto_walker) { // an explicitly chosen variant
         const Variant &v = g_variants[ctx->variant];
-        if (v.qgram && !canonical) return 2;
+        if (v.canon_minm && (!canonical || m < v.canon_minm)) return m >= 4 ? 2 : 0;
         return lds_bytes_for(v, m) <= LDS_PER_CU ? ctx->variant : 0; // buffers + halo do not fit at this m -> default
     }
     if (m < 4) return 0;
@@ -248,14 +296,19 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical)
             seen[(unsigned char)pat[i]] = true;
             ++distinct;
         }
+    auto fits = [&](int vi) { return lds_bytes_for(g_variants[vi], m) <= LDS_PER_CU; };
     if (distinct > 8) // sparse by nature (9^-4 and less): the larger tile
-        return lds_bytes_for(g_variants[VARIANT_BIG_TILE], m) <= LDS_PER_CU ? VARIANT_BIG_TILE : 0;
+        return fits(VARIANT_BIG_TILE) ? VARIANT_BIG_TILE : 0;
     // sigma^m small = matches every few bytes on a text over the pattern's alphabet (binary, m = 6: one position
     // in 64): what matters then is room to park them, and the default geometry has four times variant 2's
     double expect = 1.0;
     for (int i = 0; i < m && expect < 1e6; ++i) expect *= distinct;
     if (expect < 128.0) return 0;
-    return canonical && m >= 10 && lds_bytes_for(g_variants[VARIANT_QGRAM], m) <= LDS_PER_CU ? VARIANT_QGRAM : 2;
+    // 2 GiB ACGT: m = 8: 2.1 / 2.3 / 1.6 TB/s (skip loop / 4-gram / 8-gram), m = 9: 2.4 / 2.6 / 2.7, m = 10: 2.3 / 3.0 / 3.7,
+    // m = 16: 2.3 / 4.1 / 6.4
+    if (canonical && m >= 9 && fits(VARIANT_QGRAM8)) return VARIANT_QGRAM8;
+    if (canonical && m >= 6 && fits(VARIANT_QGRAM4)) return VARIANT_QGRAM4;
+    return 2;
 }
 
 // Convert the caller's int32 tables (or build them) into the kernel-argument layout.

@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 # bmx_shim.hip: the slots built into libbmx.so.  Every other slot (losing schedules, timing-only kernels whose
 # match lists are not valid) exists in libbmx_exp.so only and is refused by bmx_set_variant here.
-PRODUCT_VARIANTS = [0, 1, 2, 24, 25, 29]
-QGRAM_VARIANTS = [24, 25]  # 4-gram walker
+PRODUCT_VARIANTS = [0, 1, 2, 24, 25, 29, 53, 54]
+QGRAM_VARIANTS = [24, 25, 53, 54]  # 4-gram and 8-gram walkers
 
 
 def sha(a):
@@ -103,8 +103,8 @@ def test_random_texts_vs_oracle_all_variants(ctx, port):
         ctx.set_variant(0)
 
 
-def test_four_gram_walker_vs_oracle(ctx, port):
-    """The 4-gram walker (picked automatically for small alphabets; here also forced onto large
+def test_q_gram_walkers_vs_oracle(ctx, port):
+    """The 4-gram and 8-gram walkers (picked automatically for small alphabets; here also forced onto large
     ones, where its hash table has collisions): periodic and self-overlapping patterns, hits at
     every distance, m around 4 (below 4 the byte-wise walker takes over), long patterns."""
     rng = np.random.default_rng(424)
@@ -135,7 +135,7 @@ def test_four_gram_walker_vs_oracle(ctx, port):
                     pat[0] = 33 + (pat[0] - 33 + 1) % max(alpha, 2)
                 got = dev_search(ctx, text, pat.tobytes())
                 assert np.array_equal(got, port.search(text, pat.tobytes())), (v, alpha, m, n, kind)
-            if v < 0:  # the automatic choice on DNA is the 4-gram walker
+            if v < 0:  # the automatic choice on DNA is a q-gram walker on 76 KiB tiles
                 t = (rng.integers(0, 4, 100000) + 65).astype(np.uint8)
                 dev_search(ctx, t, t[50:114].tobytes())
                 assert ctx.geometry(64)["lds_bytes"] > 150000
