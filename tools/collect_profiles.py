@@ -38,6 +38,52 @@ def counter_mean(path, counter):
     return statistics.mean(vals), len(vals)
 
 
+def sq_summary(path, dst):
+    """Mean per launch of every SQ counter of the scan kernel (one --pmc pass), as a small CSV."""
+    agg, meta = {}, None
+    for r in csv.DictReader(open(path)):
+        if "scan_kernel" not in r["Kernel_Name"]:
+            continue
+        agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        meta = meta or (r["Kernel_Name"], r["Grid_Size"], r["Workgroup_Size"], r["VGPR_Count"], r["SGPR_Count"])
+    if not agg:
+        return
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "Counter_Name",
+                    "Mean_Counter_Value_Per_Launch", "Launches", "Share_Of_SQ_WAVE_CYCLES"])
+        wc = statistics.mean(agg.get("SQ_WAVE_CYCLES", [0])) or 1.0
+        for name in sorted(agg):
+            v = statistics.mean(agg[name])
+            w.writerow(list(meta) + [name, round(v), len(agg[name]), round(v / wc, 4)])
+    print("wrote", dst)
+
+
+def collect_dir(args, prof):
+    d = args.dir
+    for w in ("cfg2", "cfg3"):
+        st = glob.glob(os.path.join(d, f"stats_{w}", "*", "*_kernel_stats.csv"))
+        fe = glob.glob(os.path.join(d, f"fetch_{w}", "*", "*_counter_collection.csv"))
+        wr = glob.glob(os.path.join(d, f"write_{w}", "*", "*_counter_collection.csv"))
+        sq = glob.glob(os.path.join(d, f"sq_{w}", "*", "*_counter_collection.csv"))
+        sub = argparse.Namespace(**vars(args))
+        sub.workload, sub.dir = w, None
+        sub.stats = st[-1] if st else None
+        sub.fetch = fe[-1] if fe and wr else None
+        sub.write = wr[-1] if fe and wr else None
+        collect_one(sub, prof)
+        if sq:
+            tag = f"_{args.tag}" if args.tag else ""
+            sq_summary(sq[-1], os.path.join(prof, f"{args.round}_sq_scan_kernel{tag}_{w}.csv"))
+    for extra in ("dma_only", "ed64k", "sa2m"):
+        st = glob.glob(os.path.join(d, f"stats_{extra}", "*", "*_kernel_stats.csv"))
+        if st:
+            tag = f"_{args.tag}" if args.tag else ""
+            dst = os.path.join(prof, f"{args.round}_kernel_stats{tag}_{extra}.csv")
+            shutil.copyfile(st[-1], dst)
+            print("wrote", dst)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--round", default="r01")
@@ -47,9 +93,16 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--bytes", type=int, default=4 << 30, help="algorithmic bytes per launch")
+    ap.add_argument("--dir", help="a directory written by tools/profile_round.sh (gpurun_out/prof_<tag>): take everything in it")
     args = ap.parse_args()
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
+    if args.dir:
+        return collect_dir(args, prof)
+    collect_one(args, prof)
+
+
+def collect_one(args, prof):
     tag = f"_{args.tag}" if args.tag else ""
     if args.stats:
         dst = os.path.join(prof, f"{args.round}_kernel_stats{tag}_{args.workload}.csv")
