@@ -47,7 +47,8 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long total = *count;
     const uint32_t scan_err = bucket_overflow[1]; // raised by finish_parked (bmx_scan_common.h): the list is incomplete
-    const bool ordered = out != nullptr && *bucket_overflow == 0 && total <= cap; // block-uniform
+    const uint32_t dense = bucket_overflow[2];    // raised by a workgroup that met a dense tile: the list comes from the fill pass
+    const bool ordered = out != nullptr && *bucket_overflow == 0 && dense == 0 && total <= cap; // block-uniform
 
     uint4 *cnt4 = reinterpret_cast<uint4 *>(bucket_cnt);
     const uint4 c0 = cnt4[2 * tid], c1 = cnt4[2 * tid + 1];
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
     }
     __syncthreads(); // every thread's stores to out[] are issued and acknowledged before the release below
     if (tid == 0) {
-        const uint64_t needs_sort = (out != nullptr && !ordered && total > 1) ? 1 : 0; // host sorts the unordered list
+        // 0: the list is there and ordered; 1: complete but unordered, bmx_search_device_finish sorts it; 2: dense --
+        // only counted, bmx_search_device_finish runs the fill pass
+        const uint64_t needs_sort = dense != 0 ? (out != nullptr ? 2 : 0) : ((out != nullptr && !ordered && total > 1) ? 1 : 0);
         status[0] = total;
         status[1] = needs_sort;
         // what bmx_count_to_device publishes: a list that is not ordered yet counts as larger than any slot
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
         count[0] = 0;
         bucket_overflow[0] = 0;
         bucket_overflow[1] = 0;
+        bucket_overflow[2] = 0;
         // the host polls host_status[2] (pinned, fine-grained) for this search's sequence number
         host_status[0] = total;
         host_status[1] = needs_sort;
@@ -111,6 +115,35 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
     }
     cnt4[2 * tid] = make_uint4(0, 0, 0, 0);
     cnt4[2 * tid + 1] = make_uint4(0, 0, 0, 0);
+}
+
+// Exclusive scan of the per-tile match counts (dense results): tile_base[t] = matches in tiles before t.  One
+// workgroup; a 4 GiB text has 55 k tiles of 76 KiB = 54 rounds.
+__global__ __launch_bounds__(ORDER_THREADS) void tile_scan_kernel(const uint32_t *tile_count, uint64_t n_tiles, uint64_t *tile_base)
+{
+    __shared__ uint64_t wave_total[ORDER_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n_tiles; base += ORDER_THREADS) {
+        const uint64_t i = base + tid;
+        const uint64_t v = i < n_tiles ? tile_count[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t x = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += x;
+        }
+        if (lane == 63) wave_total[wave] = incl;
+        __syncthreads();
+        uint64_t before = carry, all = 0;
+        for (uint32_t w = 0; w < ORDER_THREADS / 64; ++w) {
+            if (w < wave) before += wave_total[w];
+            all += wave_total[w];
+        }
+        if (i < n_tiles) tile_base[i] = before + incl - v;
+        carry += all;
+        __syncthreads();
+    }
 }
 
 constexpr int SMALL_SORT_MAX = 8192; // 64 KiB of LDS

@@ -16,6 +16,7 @@
 namespace bmx {
 
 constexpr int MAX_PATTERN = 512; // == BMX_MAX_PATTERN
+constexpr int MAX_MULTI = 8;     // == BMX_MAX_MULTI: patterns per pass of bmx_search_device_multi
 constexpr int ORDER_BUCKETS = 8192;
 constexpr int ORDER_BUCKET_CAP = 8;
 
@@ -46,7 +47,23 @@ struct ScanArgs {
     uint32_t *bucket_overflow; // set to 1 when a bucket is full
     uint32_t *err;           // set to 1 when a workgroup gave up waiting for its slot reservation (finish_parked):
                              // order_kernel hands it to the host, bmx_search_device_finish returns BMX_ERR_HIP
+    // Dense results (more matches in a tile than its workgroup can park in LDS): the scan then only COUNTS
+    // -- per tile, into tile_count[] -- and raises *dense; bmx_search_device_finish takes an exclusive scan of
+    // the tile counts and runs the FILL pass (scan_kernel MODE 9), which writes every tile's matches, in
+    // ascending order, at tile_base[tile]: no atomics, no sort, whatever the density.
+    uint32_t *tile_count;      // matches per tile (NULL: not recorded; with dense == NULL the old direct path is taken)
+    uint32_t *dense;
+    const uint64_t *tile_base; // fill pass only
     uint32_t bucket_shift;
+    // Several patterns in one pass (bmx_search_device_multi; K == 0: the ordinary search).  `multi` is a blob of
+    // multi_bytes bytes, per pattern [bad: 256 x u16 | good: m x u16, padded to 16 B | pattern, padded to 16 B] at
+    // multi_off[k]; the kernel copies it into LDS as it is.  Pattern k files its matches into the position buckets
+    // [k * bucket_stride, (k + 1) * bucket_stride): the ordering kernel then writes pattern 0's ascending list,
+    // then pattern 1's, ... without knowing about patterns.
+    const uint8_t *multi;
+    uint32_t multi_bytes, K, bucket_stride;
+    uint16_t multi_off[MAX_MULTI], multi_m[MAX_MULTI];
+    uint64_t multi_own_end[MAX_MULTI]; // one past the last window start to report, per pattern (aligned coordinates)
     unsigned long long *stamps; // MODE 5 only (diagnostic build): per-wave cycle sums, 8 words per wave
     uint32_t m;
     uint32_t halo16;         // (m-1) rounded up to a multiple of 16
@@ -82,7 +99,7 @@ __device__ __forceinline__ void dma16(const uint8_t *gsrc_lane, const uint8_t *l
 // offset to report.  Every match goes to the unordered list (always complete up
 // to cap: the fallback for dense results) and to its position bucket, from which
 // order_kernel writes the ascending list without a sort.
-__device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint64_t pos, bool feed_buckets = true)
+__device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint64_t pos, bool feed_buckets = true, uint32_t pat_id = 0)
 {
     const uint64_t active = __ballot(1);
     const uint32_t lane = __lane_id();
@@ -98,7 +115,7 @@ __device__ __forceinline__ void emit_hit(const ScanArgs &a, uint64_t local, uint
             *a.bucket_overflow = 1u;
             return;
         }
-        const uint32_t b = (uint32_t)(local >> a.bucket_shift);
+        const uint32_t b = pat_id * a.bucket_stride + (uint32_t)(local >> a.bucket_shift);
         const uint32_t s = atomicAdd(&a.bucket_cnt[b], 1u);
         if (s < (uint32_t)ORDER_BUCKET_CAP)
             a.bucket_store[(uint64_t)b * ORDER_BUCKET_CAP + s] = pos;
@@ -121,6 +138,13 @@ struct LdsTables {
     uint32_t stage_seen;  // its value when this tile's walk began
     lds_u32 *stage_area;  // [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
     uint32_t stage_cap;   // entries per buffer
+    uint32_t pat_id;      // which pattern of a multi-pattern pass these tables belong to (else 0): bits 20.. of a parked entry
+    lds_u32 *wsum;        // 32 words: per-wave totals of the workgroup scans (count-only mode, fill pass)
+    // where a walker's matches go: 0 = the parking buffer (the scan), 1 = nowhere, this lane only counts them
+    // (a workgroup that met a dense tile; first half of the fill pass), 2 = out[write_at++] (second half of the fill pass)
+    mutable uint32_t sink; // (a lane of the scan switches itself to 1 the moment it finds the parking buffer full)
+    mutable uint32_t lane_cnt;
+    mutable uint64_t write_at;
     uint32_t m;
     // scalar copies for the skip-loop walker
     uint32_t b_last, p3, g1, g2, g3;
@@ -140,6 +164,15 @@ struct LdsTables {
 // the 12.6 M matches above still took 3.0 ms.  What does not fit in the buffer goes the direct way.
 __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &tb, uint64_t astart, uint64_t tile_off)
 {
+    if (tb.sink == 1) { // wave-uniform
+        ++tb.lane_cnt;
+        return;
+    }
+    if (tb.sink == 2) {
+        const uint64_t slot = tb.write_at++;
+        if (slot < a.cap) a.out[slot] = astart + a.out_bias;
+        return;
+    }
     if (tb.stage_cap != 0) { // wave-uniform
         const uint64_t active = __ballot(1);
         const uint32_t lane = __lane_id();
@@ -152,13 +185,19 @@ __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &t
         }
         base = __shfl(base, leader) - tb.stage_seen; // matches parked for this tile before mine
         if (base + rank < tb.stage_cap) {
-            tb.stage[base + rank] = (uint32_t)(astart - tile_off);
+            tb.stage[base + rank] = (uint32_t)(astart - tile_off) | (tb.pat_id << 20); // (a tile has fewer than 2^20 window starts)
+            return;
+        }
+        // The buffer is full: this tile is dense.  Its matches have all been COUNTED (the counter above), which
+        // is what the fill pass needs; the workgroup finds out when it collects the tile (scan_kernel).  The
+        // lanes that got here count the rest of their share privately: no more LDS atomics for them.
+        if (a.dense != nullptr) {
+            tb.sink = 1;
             return;
         }
     }
-    // the parking buffer is full (or there is none): more than stage_cap matches in this tile outgrow the
-    // position buckets anyway
-    emit_hit(a, astart - a.first, astart + a.out_bias, tb.stage_cap == 0);
+    // no parking buffer, or a kernel without a fill pass: the direct way, one global atomic per wave and event
+    emit_hit(a, astart - a.first, astart + a.out_bias, tb.stage_cap == 0, tb.pat_id);
 }
 
 // Second half of an append (all threads of the workgroup, `n` > 0 matches of the tile at `tile_off`
@@ -203,11 +242,12 @@ __device__ __forceinline__ void finish_parked(const ScanArgs &a, const LdsTables
     const bool buckets = n <= 2u * ORDER_BUCKET_CAP;
     if (!buckets && tid == 0) *a.bucket_overflow = 1u;
     for (uint32_t j = tid; j < n; j += BLOCK) {
-        const uint64_t astart = tile_off + buf[j];
+        const uint32_t entry = buf[j];
+        const uint64_t astart = tile_off + (entry & 0xFFFFFu);
         const uint64_t pos = astart + a.out_bias;
-        if (base + j < a.cap) a.out[base + j] = pos;
+        if (base + j < a.cap) a.out[base + j] = pos; // (unordered; in a multi-pattern pass only the bucket path below counts)
         if (buckets) {
-            const uint32_t b = (uint32_t)((astart - a.first) >> a.bucket_shift);
+            const uint32_t b = (entry >> 20) * a.bucket_stride + (uint32_t)((astart - a.first) >> a.bucket_shift);
             const uint32_t slot = atomicAdd(&a.bucket_cnt[b], 1u);
             if (slot < (uint32_t)ORDER_BUCKET_CAP)
                 a.bucket_store[(uint64_t)b * ORDER_BUCKET_CAP + slot] = pos;
@@ -465,12 +505,98 @@ __device__ __forceinline__ void walk_lane_short(const ScanArgs &a, const LdsTabl
         // window starts d..d+3, of which [lo, hi) are this lane's
         if (d < lo) e &= 0xffffffffu << (8u * (lo - d));
         if (d + 4 > hi) e &= 0xffffffffu >> (8u * (d + 4 - hi));
+        if (tb.sink == 1) { // count only (wave-uniform): one 0x80 per match
+            tb.lane_cnt += (uint32_t)__popc(e);
+            e = 0;
+        }
         while (e != 0) {
             const uint32_t j = (uint32_t)(__ffs((int)e) - 1) >> 3;
             report_hit(a, tb, tile_off + (uint64_t)(d + j), tile_off);
             e &= e - 1;
         }
         cur = nxt;
+    }
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP steps (row shifts, then the row broadcasts of
+// gfx9): VALU only -- __shfl_up goes through the LDS crossbar (ds_bpermute) and costs an lgkmcnt round trip per step.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// Fill pass for m = 1..3 (dense results are what short patterns produce: one position in four on DNA): the
+// workgroup's waves take consecutive sixteenths of the tile, and INSIDE a wave the lanes interleave by 16-byte
+// chunk -- in round r lane l tests the sixteen window starts of chunk 64 r + l of the wave's piece -- so that
+// position order is (wave, round, lane, byte) and the matches of a round go to consecutive output slots from
+// consecutive lanes: coalesced 8-byte stores.  (A lane that owns a long run of window starts, as in the walkers
+// above, scatters its matches 64 lines wide per instruction.)  The match masks of the counting half stay in
+// registers for the writing half; the scans are DPP.  One barrier inside: every wave of the workgroup is here.
+template <uint32_t BLOCK, uint32_t TILE>
+__device__ __forceinline__ void fill_tile_short(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo_t,
+                                                uint32_t hi_t, uint64_t tile_off, uint64_t tile_out, uint32_t wave,
+                                                uint32_t lane)
+{
+    constexpr uint32_t WAVES = BLOCK / 64, PIECE = TILE / WAVES, ROUNDS = (PIECE + 1023) / 1024;
+    static_assert(TILE % (WAVES * 16) == 0, "a wave's piece is a whole number of 16-byte chunks");
+    const uint32_t m = tb.m; // 1..3, wave-uniform
+    const uint32_t p0 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[0]) * 0x01010101u;
+    const uint32_t p1 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 1 ? 1 : 0]) * 0x01010101u;
+    const uint32_t p2 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 2 ? 2 : 0]) * 0x01010101u;
+    // window starts of this wave's piece that are to be reported: [lo_w, hi_w)
+    const uint32_t lo_w = lo_t > wave * PIECE ? lo_t : wave * PIECE;
+    const uint32_t hi_w = hi_t < (wave + 1) * PIECE ? hi_t : (wave + 1) * PIECE;
+    // bit j of the result: a match starts at byte j of the dword `cur` (exact zero-byte test, then the four 0x80 flags
+    // gathered into a nibble by one multiplication)
+    auto mask_of = [&](uint32_t cur, uint32_t nxt) -> uint32_t {
+        uint32_t e = eq_bytes(cur, p0);
+        if (m > 1) e &= eq_bytes(__builtin_amdgcn_alignbyte(nxt, cur, 1), p1);
+        if (m > 2) e &= eq_bytes(__builtin_amdgcn_alignbyte(nxt, cur, 2), p2);
+        return (((e >> 7) * 0x00204081u) >> 21) & 0xfu;
+    };
+    const uint32_t first = wave * PIECE + lane * 16;
+    uint32_t e[ROUNDS]; // per round: one bit per window start of this lane's 16-byte chunk
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+        const uint32_t d = first + r * 1024; // (chunks past the piece -- the last round of a 4.25 KiB piece -- are masked off)
+        const u32x4 v = *(lds_c128 *)to_lds(T + d);
+        const uint32_t nx = *(lds_c32 *)to_lds(T + d + 16);
+        uint32_t x = mask_of(v.x, v.y) | (mask_of(v.y, v.z) << 4) | (mask_of(v.z, v.w) << 8) | (mask_of(v.w, nx) << 12);
+        if (d < lo_w || d + 16 > hi_w) { // a chunk on the edge of what this wave reports (rare)
+            const uint32_t from = d < lo_w ? (lo_w - d < 16 ? lo_w - d : 16) : 0, to = d + 16 > hi_w ? (hi_w > d ? hi_w - d : 0) : 16;
+            x &= from < to ? (0xffffu << from) & (0xffffu >> (16 - to)) : 0u;
+        }
+        e[r] = x;
+        cnt += (uint32_t)__popc(x);
+    }
+    const uint32_t wave_total = __builtin_amdgcn_readlane(wave_inclusive_scan(cnt), 63);
+    if (lane == 0) tb.wsum[wave] = wave_total;
+    __syncthreads();
+    uint64_t at = tile_out;
+    for (uint32_t w = 0; w < wave; ++w) at += tb.wsum[w];
+    if (wave_total == 0) return;
+#pragma unroll
+    for (uint32_t r = 0; r < ROUNDS; ++r) {
+        uint32_t x = e[r];
+        const uint32_t c = (uint32_t)__popc(x);
+        const uint32_t incl = wave_inclusive_scan(c);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        uint64_t slot = at + (incl - c);
+        const uint64_t pos0 = tile_off + (uint64_t)(first + r * 1024) + a.out_bias;
+        while (x != 0) {
+            const uint32_t j = (uint32_t)(__ffs((int)x) - 1);
+            if (slot < a.cap) a.out[slot] = pos0 + j;
+            ++slot;
+            x &= x - 1;
+        }
+        at += total;
     }
 }
 
@@ -734,6 +860,12 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
         tb.qtab = s_q8;
         end = s_q8 + QGRAM_TABLE;
     }
+    tb.wsum = (lds_u32 *)to_lds(end);
+    end += 128;
+    tb.sink = 0;
+    tb.pat_id = 0;
+    tb.lane_cnt = 0;
+    tb.write_at = 0;
     // parking area for matches: [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
     tb.stage_cap = a.stage_cap;
     tb.stage = tb.stage_cnt = tb.stage_area = nullptr;

@@ -32,6 +32,8 @@
 
 namespace bmx {
 
+// MODE 9: the FILL pass for dense results (see scan_body): every tile walked twice, matches written in ascending
+// order at tile_base[tile] + (exclusive scan of the lanes' counts).
 // AUX: cache-policy bits of the DMA (0 default, 2 = nt: the text is read once).
 // MODE 0 is the product; MODE 1 (DMA only, no walkers) and MODE 2 (walkers only:
 // each workgroup loads its first two tiles and keeps re-walking them) exist for
@@ -42,6 +44,7 @@ namespace bmx {
 // kernels' walker for short patterns).
 // WALK 7 / 8: skip loop by quad-SAD on the pattern's last 4 (m >= 4) / 8 (m >= 8) bytes, match and shift by the
 // reference's rule at every stop (walk_lane_sad, bmx_scan_common.h): no dependent LDS chain.
+// WALK 20: K patterns in one pass (bmx_search_device_multi): the byte-wise walker once per pattern over each tile.
 // WALK 9: byte-wise walker behind a 128-bit set of the pattern's characters in scalar registers (the shift table in
 // LDS is only read for windows that end in a character of the pattern).  WALK 10: 8-gram walker, m >= 8.
 // (A WALK 1 that fetched the last four characters with one unaligned ds_read_b32 was
@@ -94,7 +97,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     const uint32_t lane = tid & 63;
     const bool is_loader = NL > 0 && (YOUNG ? wave >= (uint32_t)(NW - NL) : wave < (uint32_t)NL); // wave-uniform
     const uint32_t iwave = YOUNG ? wave - (uint32_t)(NW - NL) : wave; // index among the loaders (meaningless otherwise)
-    LdsTables tb = load_tables<WALK == 2, WALK == 3 ? 4 : (WALK == 10 ? 8 : 0)>(a, smem + 2 * buf_bytes, tid, BLOCK, smem);
+    // WALK 20 (several patterns in one pass): their tables, one blob, sit between the tile buffers and the rest
+    uint8_t *multi_lds = smem + 2 * buf_bytes;
+    const uint32_t multi_bytes = WALK == 20 ? a.multi_bytes : 0u;
+    if (WALK == 20)
+        for (uint32_t i = tid * 16; i < multi_bytes; i += BLOCK * 16)
+            *reinterpret_cast<uint4 *>(multi_lds + i) = *reinterpret_cast<const uint4 *>(a.multi + i);
+    LdsTables tb = load_tables<WALK == 2, WALK == 3 ? 4 : (WALK == 10 ? 8 : 0)>(a, smem + 2 * buf_bytes + multi_bytes, tid, BLOCK, smem);
 
     const uint32_t nchunk = buf_bytes >> 4; // 16-B chunks per tile incl. halo
     // PRIO: the waves that are still issuing their share of the DMA outrank the ones that already walk (the
@@ -195,10 +204,21 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             const uint32_t pp = (it & 1u) ^ 1u;
             if (it != 0) {
                 const uint32_t now = __builtin_amdgcn_readfirstlane(parked_now);
-                prev_n = now - seen[pp];
+                const uint32_t n_true = now - seen[pp]; // every match of that tile was counted, parked or not
                 seen[pp] = now;
-                prev_n = prev_n < tb.stage_cap ? prev_n : tb.stage_cap;
-                if (prev_n != 0 && tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
+                if (a.dense != nullptr && (tb.sink == 1 || n_true > tb.stage_cap)) {
+                    // a dense tile: nothing of it is stored -- the fill pass will write the whole list -- and from here
+                    // on this workgroup only counts (per lane, one LDS add per wave and tile instead of one per event)
+                    if (tid == 0) {
+                        *a.dense = 1u;
+                        if (n_true != 0) (void)__hip_atomic_fetch_add(a.count, (unsigned long long)n_true, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    tb.sink = 1;
+                } else {
+                    prev_n = n_true < tb.stage_cap ? n_true : tb.stage_cap;
+                    if (prev_n != 0 && tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
+                }
+                if (tid == 0 && a.tile_count != nullptr) a.tile_count[t_prev - a.tile_begin] = n_true;
             }
             tb.stage = park_buf(it & 1u);
             tb.stage_cnt = park_cnt(it & 1u);
@@ -223,27 +243,78 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         const uint64_t rem = a.own_end - tile_off; // > 0 because t < tile_end
         if (rem < (uint64_t)hi) hi = (uint32_t)rem;
 
-        if constexpr (WALK == 7 || WALK == 8) { // quad-SAD skip loop: lanes own filter positions, not window starts
-            static_assert(LOADERS == 0, "");
-            static_assert((uint32_t)BLOCK * SAD_SEG >= TILE + 16, "the lanes' filter positions must cover a tile");
-            const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
-            const uint32_t hi_t = rem < (uint64_t)TILE ? (uint32_t)rem : TILE;
-            if (MODE != 1) walk_lane_sad<WALK == 8>(a, tb, T, tid, lo_t, hi_t, tile_off);
-        } else if (MODE != 1 && (!is_loader || SEGI > 0) && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi) {
-            if constexpr (WALK == 3)
-                walk_lane_qgram(a, tb, T, lo, hi, tile_off);
-            else if constexpr (WALK == 10)
-                walk_lane_qgram8(a, tb, T, lo, hi, tile_off);
-            else if constexpr (WALK == 9)
-                walk_lane_bitmap(a, tb, T, lo, hi, tile_off);
-            else if constexpr (WALK == 4)
-                walk_lane_spec(a, tb, T, lo, hi, tile_off);
-            else if constexpr (WALK == 5)
-                walk_lane_b8(a, tb, T, lo, hi, tile_off);
-            else if constexpr (WALK == 6)
-                walk_lane_short(a, tb, T, lo, hi, tile_off);
-            else
-                walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
+        auto walk_tile = [&]() {
+            if constexpr (WALK == 7 || WALK == 8) { // quad-SAD skip loop: lanes own filter positions, not window starts
+                static_assert(LOADERS == 0, "");
+                static_assert((uint32_t)BLOCK * SAD_SEG >= TILE + 16, "the lanes' filter positions must cover a tile");
+                const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
+                const uint32_t hi_t = rem < (uint64_t)TILE ? (uint32_t)rem : TILE;
+                if (MODE != 1) walk_lane_sad<WALK == 8>(a, tb, T, tid, lo_t, hi_t, tile_off);
+            } else if (MODE != 1 && (!is_loader || SEGI > 0) && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi) {
+                if constexpr (WALK == 20) { // one walk per pattern over the tile that was fetched once
+                    for (uint32_t k = 0; k < a.K; ++k) {
+                        LdsTables tk = tb;
+                        const uint32_t mk = a.multi_m[k];
+                        tk.m = mk;
+                        tk.pat_id = k;
+                        tk.bad = reinterpret_cast<const uint16_t *>(multi_lds + a.multi_off[k]);
+                        tk.good = tk.bad + 256;
+                        tk.pat = reinterpret_cast<const uint8_t *>(tk.good) + ((2 * mk + 15) & ~15u);
+                        uint32_t hk = seg_lo + seg_len;
+                        const uint64_t remk = a.multi_own_end[k] > tile_off ? a.multi_own_end[k] - tile_off : 0;
+                        if (remk < (uint64_t)hk) hk = (uint32_t)remk;
+                        if (lo < hk) walk_lane<false>(a, tk, T, lo, hk, tile_off);
+                    }
+                } else if constexpr (WALK == 3)
+                    walk_lane_qgram(a, tb, T, lo, hi, tile_off);
+                else if constexpr (WALK == 10)
+                    walk_lane_qgram8(a, tb, T, lo, hi, tile_off);
+                else if constexpr (WALK == 9)
+                    walk_lane_bitmap(a, tb, T, lo, hi, tile_off);
+                else if constexpr (WALK == 4)
+                    walk_lane_spec(a, tb, T, lo, hi, tile_off);
+                else if constexpr (WALK == 5)
+                    walk_lane_b8(a, tb, T, lo, hi, tile_off);
+                else if constexpr (WALK == 6)
+                    walk_lane_short(a, tb, T, lo, hi, tile_off);
+                else
+                    walk_lane<WALK == 2>(a, tb, T, lo, hi, tile_off);
+            }
+        };
+        auto wave_sum = [&](uint32_t v) -> uint32_t { return __builtin_amdgcn_readlane(wave_inclusive_scan(v), 63); };
+        if constexpr (MODE == 9) {
+            // FILL pass (bmx_search_device_finish, dense results): count this lane's matches, take the exclusive
+            // scan over the workgroup's lanes -- lanes own ascending pieces of the tile, so lane order is position
+            // order --, then walk again and write each match at its final place.  No atomics, no sort.
+            static_assert(LOADERS == 0 && GRADE == 0 && WALK != 7 && WALK != 8, "lane order must be position order");
+            if constexpr (WALK == 6) { // m = 1..3: lanes interleaved by dword, coalesced stores
+                const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
+                const uint32_t hi_t = rem < (uint64_t)TILE ? (uint32_t)rem : TILE;
+                fill_tile_short<BLOCK, TILE>(a, tb, T, lo_t, hi_t, tile_off, a.tile_base[t - a.tile_begin], wave, lane);
+            } else {
+            tb.sink = 1;
+            tb.lane_cnt = 0;
+            walk_tile();
+            const uint32_t mine = tb.lane_cnt;
+            const uint32_t incl = wave_inclusive_scan(mine);
+            if (lane == 63) tb.wsum[wave] = incl;
+            __syncthreads(); // (the next tile's top barrier separates these reads from the next writes)
+            uint32_t before = 0;
+            for (uint32_t w = 0; w < wave; ++w) before += tb.wsum[w];
+            tb.sink = 2;
+            tb.write_at = a.tile_base[t - a.tile_begin] + before + (incl - mine);
+            if (mine != 0) walk_tile(); // (per lane: a lane without matches has nothing to write)
+            }
+        } else {
+            walk_tile();
+            if (a.dense != nullptr && tb.stage_cap != 0) { // lanes in count-only mode (dense tiles): one LDS add per wave and tile
+                const uint32_t c = wave_sum(tb.lane_cnt);
+                tb.lane_cnt = 0;
+                if (lane == 0 && c != 0) {
+                    const uint32_t addr = (uint32_t)(uintptr_t)tb.stage_cnt;
+                    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(c) : "memory");
+                }
+            }
         }
         if (issue_now && issue_late) issue_tile(tn, cur ? buf0 : buf1);
         if (prev_n != 0) // the previous tile's matches: reserved before this tile's DMA, stored now
@@ -262,12 +333,20 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         const uint32_t pp = (it & 1u) ^ 1u;
-        uint32_t prev_n = __builtin_amdgcn_readfirstlane(*park_cnt(pp)) - seen[pp];
-        prev_n = prev_n < tb.stage_cap ? prev_n : tb.stage_cap;
-        if (prev_n != 0) {
-            unsigned long long reserved = 0;
-            if (tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
-            finish_parked<BLOCK>(a, tb, t_prev * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
+        const uint32_t n_true = __builtin_amdgcn_readfirstlane(*park_cnt(pp)) - seen[pp];
+        if (tid == 0 && a.tile_count != nullptr) a.tile_count[t_prev - a.tile_begin] = n_true;
+        if (a.dense != nullptr && (tb.sink == 1 || n_true > tb.stage_cap)) {
+            if (tid == 0) {
+                *a.dense = 1u;
+                if (n_true != 0) (void)__hip_atomic_fetch_add(a.count, (unsigned long long)n_true, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            const uint32_t prev_n = n_true < tb.stage_cap ? n_true : tb.stage_cap;
+            if (prev_n != 0) {
+                unsigned long long reserved = 0;
+                if (tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
+                finish_parked<BLOCK>(a, tb, t_prev * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
+            }
         }
     }
     if ((MODE == 5 || MODE == 8) && a.stamps != nullptr && lane == 0) {

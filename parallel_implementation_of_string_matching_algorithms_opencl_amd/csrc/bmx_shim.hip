@@ -74,6 +74,10 @@ struct Variant {
                     // canonical shift tables and a pattern of at least this length; 0: any tables, any m
     void (*kernel)(const bmx::ScanArgs); // nullptr: this slot is not built into this library
     void (*kernel_short)(const bmx::ScanArgs);
+    // the fill pass of this geometry for dense results (m >= 4 / m < 4); nullptr: the kernel appends dense tiles the
+    // direct way (global atomics) and bmx_search_device_finish sorts
+    void (*fill)(const bmx::ScanArgs);
+    void (*fill_short)(const bmx::ScanArgs);
 };
 
 // The slot numbers are stable (tools/ and the notes in DESIGN.md refer to them), but the PRODUCT library
@@ -83,7 +87,7 @@ struct Variant {
 // only in libbmx_exp.so, the same sources compiled with -DBMX_EXPERIMENTS for tools/ (BMX_LIB=exp).
 // bmx_set_variant() refuses a slot that is not built: no caller of the shipped C ABI can select a kernel
 // that returns a wrong match list (tests/test_gpu_parity.py::test_product_library_accepts_only_its_variants).
-#define BMX_ABSENT {0, 0, 0, 0, 0, 0, false, false, 0, nullptr, nullptr}
+#define BMX_ABSENT {0, 0, 0, 0, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr}
 #ifdef BMX_EXPERIMENTS
 #define BMX_EXP(...) __VA_ARGS__
 #else
@@ -95,18 +99,23 @@ struct Variant {
 #define BMX_TILE_G(B, S, AUX, MODE, W, L, SI, G) \
     {0, B, S, 2, L, SI, (MODE) == 5 || (MODE) == 8, (W) == 3 || (W) == 10, \
      (W) == 3 || (W) == 7 || (W) == 9 ? 4 : ((W) == 8 || (W) == 10 ? 8 : 0), \
-     bmx::scan_kernel<B, S, AUX, MODE, W, L, SI, G>, bmx::scan_kernel<B, S, AUX, MODE, 6, L, SI, G>}
+     bmx::scan_kernel<B, S, AUX, MODE, W, L, SI, G>, bmx::scan_kernel<B, S, AUX, MODE, 6, L, SI, G>, nullptr, nullptr}
+// a product geometry: with the fill pass for dense results (byte-wise walker / short-pattern walker on the same tiles)
+#define BMX_TILE_F(B, S, AUX, W) \
+    {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 3 ? 4 : ((W) == 10 ? 8 : 0), bmx::scan_kernel<B, S, AUX, 0, W>, \
+     bmx::scan_kernel<B, S, AUX, 0, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>}
 #define BMX_TILE_W32(B, S, AUX, MODE, W) /* 32 waves per CU: the 80-SGPR build */ \
-    {0, B, S, 2, 0, 0, (MODE) == 5, (W) == 3, (W) == 3 ? 4 : 0, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, MODE, 6, 0>}
+    {0, B, S, 2, 0, 0, (MODE) == 5, (W) == 3, (W) == 3 ? 4 : 0, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, MODE, 6, 0>, \
+     (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 0> : nullptr, (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 6> : nullptr}
 #define BMX_RING(B, S, AUX, SKIP, MODE) BMX_RING_P(B, S, AUX, (SKIP) ? 2 : 0, MODE, 0)
 #define BMX_RING_P(B, S, AUX, W, MODE, P) \
-    {2, B, S, 3, 0, 0, (MODE) == 5, (W) == 10, (W) == 10 ? 8 : 0, bmx::scan_ring_kernel<B, S, AUX, W, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, 0, MODE, P>}
+    {2, B, S, 3, 0, 0, (MODE) == 5, (W) == 10, (W) == 10 ? 8 : 0, bmx::scan_ring_kernel<B, S, AUX, W, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, 0, MODE, P>, nullptr, nullptr}
 #define BMX_WAVE(WV, S, AUX, MODE, D, NB)                                                      \
-    {1, (WV) * 64, S, NB, 0, 0, false, false, 0, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>}
+    {1, (WV) * 64, S, NB, 0, 0, false, false, 0, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, nullptr, nullptr}
 const Variant g_variants[] = {
-    BMX_TILE(1024, 68, 2, 0, 0),                 // 0: PRODUCT -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
+    BMX_TILE_F(1024, 68, 2, 0),                  // 0: PRODUCT -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
                                                  //    (the automatic choice for m < 4 and for dense small-alphabet results)
-    BMX_TILE(1024, 68, 2, 0, 2),                 // 1: PRODUCT -- same tile, skip-loop walker
+    BMX_TILE_F(1024, 68, 2, 2),                  // 1: PRODUCT -- same tile, skip-loop walker
     BMX_TILE_W32(1024, 36, 2, 0, 2),             // 2: PRODUCT -- skip-loop walker, 36 KiB tiles, TWO workgroups = 32 waves
                                                  //    per CU (picked automatically for small alphabets, m < 10)
     BMX_EXP(BMX_TILE(768, 100, 2, 0, 0)),        // 3
@@ -132,13 +141,13 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE(512, 76, 2, 0, 0)),         // 21: same, 38 KiB tiles
     BMX_EXP(BMX_TILE(512, 132, 2, 0, 0)),        // 22: one workgroup of 8 waves, 66 KiB tiles
     BMX_EXP(BMX_TILE_W32(1024, 36, 2, 0, 0)),    // 23: variant 2's geometry with the byte-wise walker
-    BMX_TILE(1024, 68, 2, 0, 3),                 // 24: PRODUCT -- default geometry, 4-gram walker (picked automatically for
+    BMX_TILE_F(1024, 68, 2, 3),                  // 24: PRODUCT -- default geometry, 4-gram walker (picked automatically for
                                                  //     small alphabets, m >= 10)
-    BMX_TILE(1024, 36, 2, 0, 3),                 // 25: PRODUCT -- 4-gram walker, 36 KiB tiles, two workgroups per CU
+    BMX_TILE_F(1024, 36, 2, 3),                  // 25: PRODUCT -- 4-gram walker, 36 KiB tiles, two workgroups per CU
     BMX_EXP(BMX_TILE(1024, 68, 2, 0, 4)),        // 26: default geometry, byte-wise walker with two windows in flight
     BMX_EXP(BMX_TILE(1024, 68, 2, 0, 5)),        // 27: byte-wise walker on an 8-bit bad-symbol table (m <= 255 only)
     BMX_EXP(BMX_TILE(1024, 68, 2, 6, 0)),        // 28: default kernel, half of the waves issue their DMA share AFTER their walk
-    BMX_TILE(1024, 76, 2, 0, 0),                 // 29: PRODUCT -- 76 KiB tiles, room for 512 parked matches only (picked
+    BMX_TILE_F(1024, 76, 2, 0),                  // 29: PRODUCT -- 76 KiB tiles, room for 512 parked matches only (picked
                                                  //     automatically for patterns over more than 8 distinct symbols, m >= 4)
     BMX_EXP(BMX_TILE(1024, 76, 2, 0, 7)),        // 30: 76 KiB tiles, quad-SAD skip loop on the last 4 pattern bytes (valid lists; slower: DESIGN.md s5.4)
     BMX_EXP(BMX_TILE(1024, 76, 2, 0, 8)),        // 31: the same on the last 8 pattern bytes (m >= 8)
@@ -164,8 +173,8 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE(1024, 68, 2, 5, 3)),              // 50: stamps of 24 (4-gram walker)
     BMX_EXP(BMX_TILE(1024, 68, 2, 8, 3)),              // 51: clock stamps of 24
     BMX_EXP(BMX_TILE(1024, 76, 2, 0, 9)),              // 52: 76 KiB tiles, byte-wise walker behind the register bitmap (valid lists; slower)
-    BMX_TILE(1024, 76, 2, 0, 10),                      // 53: PRODUCT -- 76 KiB tiles, 8-gram walker (m >= 8)
-    BMX_TILE(1024, 76, 2, 0, 3),                       // 54: PRODUCT -- 76 KiB tiles, 4-gram walker
+    BMX_TILE_F(1024, 76, 2, 10),                       // 53: PRODUCT -- 76 KiB tiles, 8-gram walker (m >= 8)
+    BMX_TILE_F(1024, 76, 2, 3),                        // 54: PRODUCT -- 76 KiB tiles, 4-gram walker
     BMX_EXP(BMX_TILE(1024, 76, 2, 5, 9)),              // 55: stamps of 52
     BMX_EXP(BMX_TILE(1024, 76, 2, 5, 10)),             // 56: stamps of 53
     BMX_EXP(BMX_RING_P(1024, 52, 2, 0, 1, 0)),         // 57: ring, DMA only, 3 x 52 KiB
@@ -202,6 +211,13 @@ struct bmx_ctx {
     int sa_last_rounds = 0;
     int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
     unsigned long long *d_count = nullptr; // live match counter; re-armed by order_kernel
+    uint32_t *d_tile_count = nullptr;      // matches per tile of the last scan (dense results: input of the fill pass)
+    uint64_t *d_tile_base = nullptr;       // their exclusive scan
+    uint64_t tile_cap = 0;                 // tiles both arrays have room for
+    bmx::ScanArgs last_args;               // the last scan launch (the fill pass re-runs its geometry)
+    int last_grid = 0;
+    int32_t last_m = 0;
+    bool last_fillable = false;
     uint32_t *d_bucket_cnt = nullptr;      // ORDER_BUCKETS, re-armed by order_kernel
     uint64_t *d_bucket_store = nullptr;    // ORDER_BUCKETS x ORDER_BUCKET_CAP
     uint32_t *d_overflow = nullptr;
@@ -235,7 +251,7 @@ uint32_t lds_bytes_with(const Variant &v, int32_t m, uint32_t cap)
     const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
     const uint32_t waves = (uint32_t)v.block / 64u;
     const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u) + 256 +
-                            (v.qgram ? bmx::QGRAM_TABLE : 0u) + (cap ? 2u * cap * 4u + 32u : 0u);
+                            (v.qgram ? bmx::QGRAM_TABLE : 0u) + 128u + (cap ? 2u * cap * 4u + 32u : 0u);
     if (v.kind != 1) return (uint32_t)v.nbuf * ((uint32_t)unit_bytes(v) + halo16) + tables;
     return waves * v.nbuf * (64u * v.seg + halo16) + tables;
 }
@@ -370,7 +386,7 @@ int bmx_ctx_create(int device, bmx_ctx **out)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_bucket_cnt, bmx::ORDER_BUCKETS * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_bucket_store, (size_t)bmx::ORDER_BUCKETS * bmx::ORDER_BUCKET_CAP * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, 2 * sizeof(uint32_t)); // {bucket overflow, scan error}
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, 4 * sizeof(uint32_t)); // {bucket overflow, scan error, dense, -}
     if (e == hipSuccess) e = hipMalloc(&ctx->d_status, 4 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 4 * sizeof(uint64_t), hipHostMallocMapped);
     if (e == hipSuccess) {
@@ -395,6 +411,8 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_count) (void)hipFree(ctx->d_count);
+    if (ctx->d_tile_count) (void)hipFree(ctx->d_tile_count);
+    if (ctx->d_tile_base) (void)hipFree(ctx->d_tile_base);
     if (ctx->d_bucket_cnt) (void)hipFree(ctx->d_bucket_cnt);
     if (ctx->d_bucket_store) (void)hipFree(ctx->d_bucket_store);
     if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
@@ -489,7 +507,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     if (!ctx->armed) { // first use, or a previous enqueue failed half way: zero the device counters
         HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(ctx->d_bucket_cnt, 0, bmx::ORDER_BUCKETS * sizeof(uint32_t), stream));
-        HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, 2 * sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, 4 * sizeof(uint32_t), stream));
     }
     ctx->armed = false;
 
@@ -526,6 +544,9 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         a.bucket_store = ctx->d_bucket_store;
         a.bucket_overflow = ctx->d_overflow;
         a.err = ctx->d_overflow + 1;
+        a.tile_count = nullptr;
+        a.dense = nullptr;
+        a.tile_base = nullptr;
         a.bucket_shift = 0;
         a.stamps = nullptr;
         a.stage_cap = stage_cap_for(v, m);
@@ -550,6 +571,23 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         const uint64_t max_grid = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
         const uint32_t grid = (uint32_t)std::min<uint64_t>(nblocks, max_grid);
 
+        // dense results: the scan counts per tile, bmx_search_device_finish runs the fill pass of this geometry
+        auto fill = m >= 4 ? v.fill : v.fill_short;
+        ctx->last_fillable = false;
+        if (fill != nullptr && a.stage_cap != 0) a.dense = ctx->d_overflow + 2; // (count-only calls too: dense tiles are just counted)
+        if (fill != nullptr && a.stage_cap != 0 && out != nullptr) {
+            const uint64_t n_tiles = a.tile_end - a.tile_begin;
+            if (ctx->tile_cap < n_tiles) {
+                if (ctx->d_tile_count) (void)hipFree(ctx->d_tile_count);
+                if (ctx->d_tile_base) (void)hipFree(ctx->d_tile_base);
+                ctx->d_tile_count = nullptr, ctx->d_tile_base = nullptr, ctx->tile_cap = 0;
+                HIPCHK(hipMalloc(&ctx->d_tile_count, n_tiles * sizeof(uint32_t)));
+                HIPCHK(hipMalloc(&ctx->d_tile_base, n_tiles * sizeof(uint64_t)));
+                ctx->tile_cap = n_tiles;
+            }
+            a.tile_count = ctx->d_tile_count;
+            ctx->last_fillable = true;
+        }
         const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
         if (v.stamps) { // diagnostic build: room for 8 words per wave
             const uint64_t words = (uint64_t)grid * (v.block / 64) * 8;
@@ -567,6 +605,11 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
         ctx->n_timed++;
         ctx->timed = true;
+        ctx->last_args = a;
+        ctx->last_grid = (int)grid;
+        ctx->last_m = m;
+    } else {
+        ctx->last_fillable = false;
     }
 
     // ascending list from the position buckets, {count, needs_sort} for the host, counters re-armed
@@ -608,7 +651,7 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
         }
     }
     const uint64_t total = ctx->h_status[0];
-    const bool needs_sort = ctx->h_status[1] != 0;
+    const bool needs_sort = ctx->h_status[1] == 1;
     if (ctx->h_status[3] != 0) { // finish_parked (bmx_scan_common.h): matches were dropped, the list is not the answer
         set_err("scan kernel: a workgroup waited longer than its bound for a slot reservation; result discarded");
         if (n_matches) *n_matches = 0;
@@ -617,6 +660,43 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
     ctx->last_sorted = needs_sort;
     if (n_matches) *n_matches = total;
     const uint64_t stored = std::min(total, capacity);
+    // A complete but unordered list (clustered matches overflowed the position buckets) can be sorted or written
+    // anew by the fill pass; the fill pass costs a second read of the text (~n / 4 TB/s), the radix sort ~0.1 ms +
+    // 65 ns per thousand matches (16.8 M matches: 1.1 ms).
+    // (Only for patterns of 1-3 bytes, whose fill pass tests every position from registers: the byte-wise walker
+    // of the longer ones, run twice over a small alphabet, is slower than the sort -- 1 GiB ACGT, m = 4: 3.3 vs 1.9 ms.)
+    const bool fill_instead_of_sort = needs_sort && ctx->last_fillable && ctx->last_m < 4 && d_match_positions && capacity > 0 &&
+                                      (double)(ctx->last_args.data_end) / 4.0e9 < 0.1 + (double)stored * 6.5e-8;
+    if ((ctx->h_status[1] == 2 || fill_instead_of_sort) && d_match_positions && capacity > 0) {
+        // Dense result: some tile held more matches than its workgroup can park in LDS.  The scan has counted every
+        // tile's matches; their exclusive scan says where each tile's matches go, and the fill pass -- the same
+        // geometry, every tile walked twice: count per lane, scan over the workgroup, write -- puts them there in
+        // ascending order.  The text is read a second time; nothing is sorted, no atomic is issued.
+        if (!ctx->last_fillable) {
+            set_err("bmx_search_device_finish: dense result without a fill pass");
+            return BMX_ERR_HIP;
+        }
+        const Variant &v = g_variants[ctx->last_variant];
+        auto fill = ctx->last_m >= 4 ? v.fill : v.fill_short;
+        bmx::ScanArgs a = ctx->last_args;
+        const uint64_t n_tiles = a.tile_end - a.tile_begin;
+        hipLaunchKernelGGL(bmx::tile_scan_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, ctx->d_tile_count, n_tiles,
+                           ctx->d_tile_base);
+        HIPCHK(hipGetLastError());
+        a.out = d_match_positions;
+        a.cap = capacity;
+        a.stage_cap = 0;
+        a.tile_base = ctx->d_tile_base;
+        a.tile_count = nullptr;
+        a.dense = nullptr;
+        const uint32_t lds = lds_bytes_with(v, ctx->last_m, 0);
+        HIPCHK(hipFuncSetAttribute((const void *)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fill, dim3(ctx->last_grid), dim3(v.block), lds, stream, a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        ctx->last_sorted = false;
+        return total > capacity ? BMX_ERR_CAPACITY : BMX_OK;
+    }
     if (needs_sort && stored > 1 && d_match_positions) {
         // a position bucket overflowed (clustered / dense matches): order the complete unordered list
         if (stored <= (uint64_t)bmx::SMALL_SORT_MAX) {

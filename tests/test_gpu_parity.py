@@ -533,6 +533,46 @@ def test_dense_results_short_patterns(ctx, port):
         ctx.set_variant(0)
 
 
+def test_dense_results_take_the_fill_pass(ctx, port):
+    """More matches in a tile than its workgroup can park in LDS (one position in four on DNA with a one-byte
+    pattern; every position of a...a with 'aa'; SURVEY's hard case): the scan only counts, the fill pass writes
+    the list in ascending order at the places an exclusive scan of the tile counts assigns.  Mixed texts too: a
+    dense stretch in the middle of a sparse text, so that workgroups switch to counting at different tiles."""
+    rng = np.random.default_rng(2718)
+    cases = []
+    dna = (rng.integers(0, 4, 5_000_000) + 65).astype(np.uint8)
+    for m in (1, 2, 3, 4, 5):
+        cases.append((dna, dna[777:777 + m].tobytes()))
+    aaa = np.full(3_000_001, ord("a"), dtype=np.uint8)
+    cases += [(aaa, b"a"), (aaa, b"aa"), (aaa, b"aaaaaaaaaaaaaaaa"), (aaa, b"a" * 99)]
+    mixed = (rng.integers(0, 95, 6_000_000) + 32).astype(np.uint8)
+    mixed[2_000_000:2_400_000] = ord("x")
+    mixed[5_999_000:] = ord("x")
+    cases += [(mixed, b"x"), (mixed, b"xx"), (mixed, b"xxxxxxxx"), (mixed, mixed[100:108].tobytes())]
+    try:
+        for v in (-1, 0, 2, 29, 53):
+            ctx.set_variant(v)
+            for text, pat in cases:
+                want = port.search(text, pat)
+                got = dev_search(ctx, text, pat)
+                assert got.size == want.size and np.array_equal(got, want), (v, pat[:8], len(pat), got.size, want.size)
+                if len(pat) == 1:
+                    assert not ctx.last_search_sorted()  # one position in four, or all of them: the fill pass, no sort
+        # capacity smaller than the result: the true total, and the ascending PREFIX of the list
+        ctx.set_variant(-1)
+        import torch
+
+        d = torch.from_numpy(dna).cuda()
+        out = torch.zeros(1000, dtype=torch.int64, device="cuda")
+        pos, total = ctx.search_device(d, b"A", out=out)
+        want = port.search(dna, b"A")
+        assert total == want.size and np.array_equal(pos.cpu().numpy().astype(np.uint64), want[:1000])
+        # count-only call (no output buffer), as bmx_search_ranges makes it
+        assert ctx.search_ranges(dna.tobytes(), b"A", [0, dna.size - 1]).tolist() == [want.size]
+    finally:
+        ctx.set_variant(0)
+
+
 def test_two_searches_in_flight_on_two_streams(port):
     """Two contexts alternate, each on its own stream; a search's scan is released by the end of the
     other context's SCAN kernel (bmx_stream_wait_last_scan), its ordering kernel runs under the next
