@@ -174,6 +174,20 @@ int bmx_text_upload(bmx_ctx *ctx, const char *text, uint64_t n, void **d_text_ou
 int bmx_device_free(bmx_ctx *ctx, void *d_ptr);
 int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out);
 
+/* Several patterns in ONE pass over a text resident in HBM (SURVEY.md s8 f3 in full: the reference re-uploads
+ * the text and re-JITs its kernel for every query, BoyreMoore.cpp:213-256; here the text is fetched once per
+ * tile and walked once per pattern, each with its own shift tables -- BoyreMoore.cpp:150-190 -- in LDS).
+ * K = 1..BMX_MAX_MULTI patterns of ms[k] bytes.  On return d_match_positions holds pattern 0's matches in
+ * ascending order, then pattern 1's, ...: pattern k's are the n_matches[k] entries from index first[k]
+ * (n_matches and first: host arrays of K entries).  d_text, n, n_own, base_offset as in bmx_search_device.
+ * The match lists are exactly those of K calls of bmx_search_device; results too dense or too clustered for the
+ * one-pass bookkeeping are produced by exactly that, pattern by pattern (same answer, no speed-up).
+ * More matches in all than `capacity`: BMX_ERR_CAPACITY, n_matches[] still the true counts. */
+#define BMX_MAX_MULTI 8
+int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own, uint64_t base_offset,
+                            const char *const *pats, const int32_t *ms, int32_t K, uint64_t *d_match_positions,
+                            uint64_t capacity, uint64_t *n_matches, uint64_t *first, void *stream);
+
 /* ---- measurement ----------------------------------------------------------- */
 
 /* Duration of the most recent scan kernel launched through ctx, from HIP events

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
                                                               unsigned long long *count, uint32_t *bucket_cnt,
                                                               const uint64_t *bucket_store,
                                                               uint32_t *bucket_overflow, uint64_t *status,
-                                                              uint64_t *host_status, uint64_t seq)
+                                                              uint64_t *host_status, uint64_t seq,
+                                                              uint64_t *multi_first, uint32_t multi_threads_per_pattern)
 {
     __shared__ uint32_t wave_total[ORDER_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,6 +66,11 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
     if (lane == 63) wave_total[wave] = incl;
     __syncthreads(); // also: every thread has read count/overflow before they are reset below
 
+    if (multi_first != nullptr) { // a multi-pattern pass: pattern k's buckets start at thread k * multi_threads_per_pattern
+        uint32_t base = incl - mine;
+        for (uint32_t w = 0; w < wave; ++w) base += wave_total[w];
+        if (tid % multi_threads_per_pattern == 0) multi_first[tid / multi_threads_per_pattern] = base;
+    }
     if (ordered && total > 0) {
         uint32_t base = incl - mine;
         for (uint32_t w = 0; w < wave; ++w) base += wave_total[w];

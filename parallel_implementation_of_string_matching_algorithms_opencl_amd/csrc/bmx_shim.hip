@@ -28,6 +28,7 @@
 #include "bmx_scan_wave_kernel.h"
 
 static_assert(bmx::MAX_PATTERN == BMX_MAX_PATTERN, "header and kernel disagree");
+static_assert(bmx::MAX_MULTI == BMX_MAX_MULTI, "header and kernel disagree");
 
 // bmx_sort.hip
 int bmx_internal_radix_sort(uint64_t *d_keys, uint64_t n, hipStream_t stream, char *err, size_t errlen);
@@ -214,6 +215,8 @@ struct bmx_ctx {
     uint32_t *d_tile_count = nullptr;      // matches per tile of the last scan (dense results: input of the fill pass)
     uint64_t *d_tile_base = nullptr;       // their exclusive scan
     uint64_t tile_cap = 0;                 // tiles both arrays have room for
+    uint8_t *d_multi = nullptr;            // bmx_search_device_multi: the patterns' tables (one blob) and first[]
+    uint64_t *d_multi_first = nullptr;
     bmx::ScanArgs last_args;               // the last scan launch (the fill pass re-runs its geometry)
     int last_grid = 0;
     int32_t last_m = 0;
@@ -411,6 +414,8 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->d_count) (void)hipFree(ctx->d_count);
+    if (ctx->d_multi) (void)hipFree(ctx->d_multi);
+    if (ctx->d_multi_first) (void)hipFree(ctx->d_multi_first);
     if (ctx->d_tile_count) (void)hipFree(ctx->d_tile_count);
     if (ctx->d_tile_base) (void)hipFree(ctx->d_tile_base);
     if (ctx->d_bucket_cnt) (void)hipFree(ctx->d_bucket_cnt);
@@ -547,6 +552,8 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         a.tile_count = nullptr;
         a.dense = nullptr;
         a.tile_base = nullptr;
+        a.multi = nullptr;
+        a.multi_bytes = a.K = a.bucket_stride = 0;
         a.bucket_shift = 0;
         a.stamps = nullptr;
         a.stage_cap = stage_cap_for(v, m);
@@ -578,7 +585,9 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         if (fill != nullptr && a.stage_cap != 0 && out != nullptr) {
             const uint64_t n_tiles = a.tile_end - a.tile_begin;
             if (ctx->tile_cap < n_tiles) {
-                if (ctx->d_tile_count) (void)hipFree(ctx->d_tile_count);
+                if (ctx->d_multi) (void)hipFree(ctx->d_multi);
+    if (ctx->d_multi_first) (void)hipFree(ctx->d_multi_first);
+    if (ctx->d_tile_count) (void)hipFree(ctx->d_tile_count);
                 if (ctx->d_tile_base) (void)hipFree(ctx->d_tile_base);
                 ctx->d_tile_count = nullptr, ctx->d_tile_base = nullptr, ctx->tile_cap = 0;
                 HIPCHK(hipMalloc(&ctx->d_tile_count, n_tiles * sizeof(uint32_t)));
@@ -615,7 +624,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     // ascending list from the position buckets, {count, needs_sort} for the host, counters re-armed
     hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, out, capacity, ctx->d_count,
                        ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status, ctx->h_status_dev,
-                       ++ctx->seq);
+                       ++ctx->seq, (uint64_t *)nullptr, 1u);
     HIPCHK(hipGetLastError());
     ctx->armed = true;
     return BMX_OK;
@@ -720,6 +729,163 @@ int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_o
                                        d_match_positions, capacity, stream);
     if (rc != BMX_OK) return rc;
     return bmx_search_device_finish(ctx, d_match_positions, capacity, n_matches, stream);
+}
+
+// ---- several patterns in one pass ----------------------------------------
+namespace {
+constexpr uint32_t MULTI_BLOB_MAX = bmx::MAX_MULTI * (512 + 2 * ((BMX_MAX_PATTERN + 7) & ~7) + BMX_MAX_PATTERN + 32);
+const auto g_multi_kernel = bmx::scan_kernel<1024, 68, 2, 0, 20>;
+const Variant g_multi_variant = {0, 1024, 68, 2, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr};
+} // namespace
+
+int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own, uint64_t base_offset,
+                            const char *const *pats, const int32_t *ms, int32_t K, uint64_t *d_match_positions,
+                            uint64_t capacity, uint64_t *n_matches, uint64_t *first, void *stream_v)
+{
+    if (!ctx || !pats || !ms || !n_matches || !first || K < 1 || K > BMX_MAX_MULTI) return BMX_ERR_ARG;
+    if ((capacity > 0 && !d_match_positions) || (n > 0 && !d_text)) return BMX_ERR_ARG;
+    int32_t m_max = 0;
+    for (int k = 0; k < K; ++k) {
+        if (!pats[k] || ms[k] < 1 || ms[k] > BMX_MAX_PATTERN) return BMX_ERR_ARG;
+        m_max = std::max(m_max, ms[k]);
+        n_matches[k] = first[k] = 0;
+    }
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIPCHK(hipSetDevice(ctx->device));
+    // the exact way, pattern by pattern: what the one-pass result must equal, and what it falls back to
+    auto one_by_one = [&]() -> int {
+        uint64_t at = 0, total = 0;
+        for (int k = 0; k < K; ++k) {
+            uint64_t got = 0;
+            const uint64_t room = capacity > at ? capacity - at : 0;
+            const int rc = bmx_search_device(ctx, d_text, n, n_own, base_offset, pats[k], ms[k], nullptr, nullptr,
+                                             room ? d_match_positions + at : nullptr, room, &got, stream);
+            if (rc != BMX_OK && rc != BMX_ERR_CAPACITY) return rc;
+            first[k] = at;
+            n_matches[k] = got;
+            total += got;
+            at += std::min(got, room);
+        }
+        return total > capacity ? BMX_ERR_CAPACITY : BMX_OK;
+    };
+    if (K == 1 || capacity == 0) return one_by_one();
+
+    // tables of every pattern (BoyreMoore.cpp:150-190 each), laid out as the kernel keeps them in LDS
+    std::vector<uint8_t> blob;
+    bmx::ScanArgs a;
+    uint64_t n_starts_max = 0;
+    const uintptr_t addr = (uintptr_t)d_text;
+    const uint64_t mis = addr & 15u;
+    for (int k = 0; k < K; ++k) {
+        const int32_t m = ms[k];
+        int32_t bad[BMX_BAD_TABLE_SIZE];
+        std::vector<int32_t> good(m);
+        const int rc = bmx_build_tables(pats[k], m, bad, good.data());
+        if (rc != BMX_OK) return rc;
+        const size_t off = blob.size();
+        blob.resize(off + 512 + (((size_t)2 * m + 15) & ~(size_t)15) + (((size_t)m + 15) & ~(size_t)15), 0);
+        uint16_t *b16 = reinterpret_cast<uint16_t *>(blob.data() + off);
+        for (int c = 0; c < 256; ++c) b16[c] = (uint16_t)(c < BMX_BAD_TABLE_SIZE ? std::max(bad[c], 1) : m);
+        uint16_t *g16 = b16 + 256;
+        for (int i = 0; i < m; ++i) g16[i] = (uint16_t)std::max(good[i], 0);
+        std::memcpy(blob.data() + off + 512 + (((size_t)2 * m + 15) & ~(size_t)15), pats[k], (size_t)m);
+        a.multi_off[k] = (uint16_t)off;
+        a.multi_m[k] = (uint16_t)m;
+        const uint64_t n_starts = n < (uint64_t)m ? 0 : std::min<uint64_t>(n - (uint64_t)m + 1, n_own);
+        a.multi_own_end[k] = mis + n_starts;
+        n_starts_max = std::max(n_starts_max, n_starts);
+    }
+    for (int k = K; k < BMX_MAX_MULTI; ++k) a.multi_off[k] = a.multi_m[k] = 0, a.multi_own_end[k] = 0;
+    if (n_starts_max == 0) return BMX_OK;
+    if (!ctx->d_multi) HIPCHK(hipMalloc(&ctx->d_multi, MULTI_BLOB_MAX));
+    if (!ctx->d_multi_first) HIPCHK(hipMalloc(&ctx->d_multi_first, (BMX_MAX_MULTI + 1) * sizeof(uint64_t)));
+    HIPCHK(hipMemcpyAsync(ctx->d_multi, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream)); // (the blob is a local)
+
+    ctx->timed = false;
+    if (!ctx->armed) {
+        HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned long long), stream));
+        HIPCHK(hipMemsetAsync(ctx->d_bucket_cnt, 0, bmx::ORDER_BUCKETS * sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, 4 * sizeof(uint32_t), stream));
+    }
+    ctx->armed = false;
+    const Variant &v = g_multi_variant;
+    const uint64_t tile = unit_bytes(v);
+    bool canonical = true;
+    int rc = fill_tables(a.tab, pats[0], ms[0], nullptr, nullptr, &canonical); // (unused by the multi walk; keeps the block defined)
+    if (rc != BMX_OK) {
+        ctx->armed = true;
+        return rc;
+    }
+    a.text16 = (const uint8_t *)(addr - mis);
+    a.first = mis;
+    a.own_end = mis + n_starts_max;
+    a.data_end = mis + n;
+    a.out_bias = base_offset - mis;
+    a.tile_begin = 0;
+    a.tile_end = (a.own_end + tile - 1) / tile;
+    a.out = d_match_positions;
+    a.cap = capacity;
+    a.count = ctx->d_count;
+    a.bucket_cnt = ctx->d_bucket_cnt;
+    a.bucket_store = ctx->d_bucket_store;
+    a.bucket_overflow = ctx->d_overflow;
+    a.err = ctx->d_overflow + 1;
+    a.tile_count = nullptr;
+    a.dense = nullptr; // dense tiles take the direct path, raise the overflow flag and send the call the exact way
+    a.tile_base = nullptr;
+    a.stamps = nullptr;
+    a.m = (uint32_t)m_max;
+    a.halo16 = ((uint32_t)(m_max - 1) + 15u) & ~15u;
+    a.multi = ctx->d_multi;
+    a.multi_bytes = (uint32_t)blob.size();
+    a.K = (uint32_t)K;
+    uint32_t kp2 = 1;
+    while ((int)kp2 < K) kp2 <<= 1;
+    a.bucket_stride = (uint32_t)bmx::ORDER_BUCKETS / kp2;
+    a.bucket_shift = 0;
+    while (((n_starts_max - 1) >> a.bucket_shift) >= (uint64_t)a.bucket_stride) ++a.bucket_shift;
+    const uint32_t lds_fixed = 2u * ((uint32_t)tile + a.halo16) + a.multi_bytes + 512 + ((((uint32_t)m_max + 7u) & ~7u) * 2) +
+                               (((uint32_t)m_max + 15u) & ~15u) + 256 + 128;
+    a.stage_cap = 0;
+    for (uint32_t cap = 1024; cap >= 128 && a.stage_cap == 0; cap /= 2)
+        if (lds_fixed + 2 * cap * 4 + 32 <= LDS_PER_CU) a.stage_cap = cap;
+    const uint32_t lds = lds_fixed + (a.stage_cap ? 2 * a.stage_cap * 4 + 32 : 0);
+    if (lds > LDS_PER_CU) {
+        ctx->armed = true;
+        return one_by_one();
+    }
+    static int multi_attr = 0;
+    if (multi_attr < (int)lds) {
+        HIPCHK(hipFuncSetAttribute((const void *)g_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        multi_attr = (int)lds;
+    }
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(a.tile_end - a.tile_begin, (uint64_t)ctx->num_cu);
+    const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
+    HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
+    hipLaunchKernelGGL(g_multi_kernel, dim3(grid), dim3(v.block), lds, stream, a);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
+    ctx->n_timed++;
+    ctx->timed = true;
+    ctx->last_fillable = false;
+    hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, d_match_positions, capacity, ctx->d_count,
+                       ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status, ctx->h_status_dev, ++ctx->seq,
+                       ctx->d_multi_first, a.bucket_stride / 8u);
+    HIPCHK(hipGetLastError());
+    ctx->armed = true;
+    uint64_t total = 0;
+    rc = bmx_search_device_finish(ctx, nullptr, 0, &total, stream); // waits for the status word; no list handling here
+    if (rc != BMX_OK && rc != BMX_ERR_CAPACITY) return rc;
+    if (ctx->h_status[1] != 0 || total > capacity) return one_by_one(); // unordered / dense / too many: the exact way
+    uint64_t h_first[BMX_MAX_MULTI + 1];
+    HIPCHK(hipMemcpyAsync(h_first, ctx->d_multi_first, kp2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    for (int k = 0; k < K; ++k) {
+        first[k] = h_first[k];
+        n_matches[k] = (k + 1 < (int)kp2 ? h_first[k + 1] : total) - h_first[k];
+    }
+    return BMX_OK;
 }
 
 int bmx_count_to_device(bmx_ctx *ctx, uint64_t *d_dst, void *stream_v)

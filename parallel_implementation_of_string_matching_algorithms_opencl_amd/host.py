@@ -30,6 +30,7 @@ if os.environ.get("BMX_LIB") == "exp":
     LIB_PATH = os.path.join(_HERE, "lib", "libbmx_exp.so")
 
 MAX_PATTERN = 512
+MAX_MULTI = 8
 BAD_TABLE_SIZE = 128
 
 OK = 0
@@ -60,6 +61,8 @@ SYMBOLS = [
     ("bmx_search_device_enqueue", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p,
                                             C.c_int32, _i32p, _i32p, C.c_void_p, C.c_uint64, C.c_void_p]),
     ("bmx_search_device_finish", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, _u64p, C.c_void_p]),
+    ("bmx_search_device_multi", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_char_p),
+                                          _i32p, C.c_int32, C.c_void_p, C.c_uint64, _u64p, _u64p, C.c_void_p]),
     ("bmx_last_search_sorted", C.c_int, [C.c_void_p]),
     ("bmx_stream_wait_last_scan", C.c_int, [C.c_void_p, C.c_void_p]),
     ("bmx_count_to_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -238,6 +241,31 @@ class Context:
                                      C.c_void_p(out.data_ptr()), cap, C.byref(total), stream)
         _check(rc, "bmx_search_device", allow=(ERR_CAPACITY,))
         return out[: min(int(total.value), cap)], int(total.value)
+
+    def search_device_multi(self, d_text, patterns, *, n: Optional[int] = None, n_own: Optional[int] = None,
+                            base_offset: int = 0, out=None, capacity: Optional[int] = None):
+        """Up to MAX_MULTI patterns in ONE pass over a text resident in HBM (bmx_search_device_multi).
+        Returns a list with one positions tensor (a view of ``out``) per pattern, each ascending."""
+        import torch
+
+        pats = [_pat_bytes(p) for p in patterns]
+        K = len(pats)
+        if n is None:
+            n = d_text.numel()
+        if n_own is None:
+            n_own = n
+        if out is None:
+            out = torch.empty(max(capacity if capacity is not None else 1 << 16, 1), dtype=torch.int64, device=d_text.device)
+        cap = out.numel() if capacity is None else min(capacity, out.numel())
+        arr = (C.c_char_p * K)(*pats)
+        ms = (C.c_int32 * K)(*[len(p) for p in pats])
+        counts = (C.c_uint64 * K)()
+        first = (C.c_uint64 * K)()
+        stream = C.c_void_p(torch.cuda.current_stream(d_text.device).cuda_stream)
+        rc = lib().bmx_search_device_multi(self._h, C.c_void_p(d_text.data_ptr()), n, n_own, base_offset, arr, ms, K,
+                                           C.c_void_p(out.data_ptr()), cap, counts, first, stream)
+        _check(rc, "bmx_search_device_multi")
+        return [out[int(first[k]): int(first[k]) + int(counts[k])] for k in range(K)]
 
     def enqueue(self, d_text, pattern, out, *, n=None, n_own=None, base_offset=0, tables=None):
         """Launch scan + ordering on torch's current stream; no synchronisation."""

@@ -573,6 +573,60 @@ def test_dense_results_take_the_fill_pass(ctx, port):
         ctx.set_variant(0)
 
 
+def test_several_patterns_in_one_pass(ctx, port):
+    """bmx_search_device_multi: K patterns walked over a text that is fetched once.  Every pattern's list must
+    be the list of its own single-pattern search (= the oracle's): mixed lengths including 1-3 bytes, equal
+    patterns, a pattern longer than the text, a misaligned text pointer, shard semantics (n_own, base_offset),
+    and sets in which one pattern is dense or clustered (the call then takes the exact way, pattern by pattern)."""
+    import torch
+
+    rng = np.random.default_rng(8128)
+    text = (rng.integers(0, 95, 5_000_000) + 32).astype(np.uint8)
+    base = [text[1000:1016].tobytes(), text[70000:70064].tobytes(), text[123456:123465].tobytes(), b"zq", text[5:10].tobytes(),
+            text[999:1098].tobytes(), text[4_000_000:4_000_512].tobytes(), text[1000:1016].tobytes()]
+    for k, pat in enumerate(base):
+        for p in rng.integers(0, text.size - 600, 40 + 10 * k):
+            text[p:p + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
+    d_all = torch.from_numpy(np.concatenate([np.zeros(5, np.uint8), text])).cuda()
+    out = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
+    for K in (1, 2, 3, 5, 8):
+        for mis in (0, 5):
+            d = d_all[5:] if mis else torch.from_numpy(text).cuda()
+            got = ctx.search_device_multi(d, base[:K], out=out)
+            assert len(got) == K
+            for k in range(K):
+                want = port.search(text, base[k])
+                assert np.array_equal(got[k].cpu().numpy().astype(np.uint64), want), (K, mis, k)
+    # shard semantics: the same cut as bmx_search_device makes
+    d = torch.from_numpy(text).cuda()
+    got = ctx.search_device_multi(d[1_000_000:3_000_600], base[:4], n_own=2_000_000, base_offset=1_000_000, out=out)
+    for k in range(4):
+        want = port.search(text[:3_000_600], base[k])
+        want = want[(want >= 1_000_000) & (want < 3_000_000)]
+        assert np.array_equal(got[k].cpu().numpy().astype(np.uint64), want), k
+    # one pattern longer than the text, one absent
+    small = torch.from_numpy(text[:50]).cuda()
+    got = ctx.search_device_multi(small, [text[10:14].tobytes(), text[0:99].tobytes() + b"x", b"~~~~~~~"], out=out)
+    assert got[0].cpu().tolist() == port.search(text[:50], text[10:14].tobytes()).tolist() and got[1].numel() == 0 and got[2].numel() == 0
+    # a dense pattern and a clustered one in the set: every list still exact
+    text2 = text.copy()
+    text2[2_000_000:2_100_000] = ord("e")
+    d2 = torch.from_numpy(text2).cuda()
+    big = torch.zeros(1 << 22, dtype=torch.int64, device="cuda")
+    pats2 = [base[0], b"e", b"ee", base[2]]
+    got = ctx.search_device_multi(d2, pats2, out=big)
+    for k, pat in enumerate(pats2):
+        assert np.array_equal(got[k].cpu().numpy().astype(np.uint64), port.search(text2, pat)), k
+    # too little room: a defined error
+    with pytest.raises(host.BmxError) as e:
+        ctx.search_device_multi(d2, pats2, out=big, capacity=1000)
+    assert e.value.rc == host.ERR_CAPACITY
+    with pytest.raises(host.BmxError):
+        ctx.search_device_multi(d, [b"a"] * 9, out=out)  # more than BMX_MAX_MULTI
+    # and the context still serves an ordinary search afterwards
+    assert np.array_equal(dev_search(ctx, text, base[0]), port.search(text, base[0]))
+
+
 def test_two_searches_in_flight_on_two_streams(port):
     """Two contexts alternate, each on its own stream; a search's scan is released by the end of the
     other context's SCAN kernel (bmx_stream_wait_last_scan), its ordering kernel runs under the next
