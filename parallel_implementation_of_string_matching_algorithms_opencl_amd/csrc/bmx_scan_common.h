@@ -44,16 +44,17 @@ struct ScanArgs {
     // shard-local start lies in [b << bucket_shift, (b+1) << bucket_shift).
     uint32_t *bucket_cnt;    // ORDER_BUCKETS counters
     uint64_t *bucket_store;  // ORDER_BUCKETS x ORDER_BUCKET_CAP offsets
-    uint32_t *bucket_overflow; // set to 1 when a bucket is full
-    uint32_t *err;           // set to 1 when a workgroup gave up waiting for its slot reservation (finish_parked):
-                             // order_kernel hands it to the host, bmx_search_device_finish returns BMX_ERR_HIP
-    // Dense results (more matches in a tile than its workgroup can park in LDS): the scan then only COUNTS
-    // -- per tile, into tile_count[] -- and raises *dense; bmx_search_device_finish takes an exclusive scan of
-    // the tile counts and runs the FILL pass (scan_kernel MODE 9), which writes every tile's matches, in
-    // ascending order, at tile_base[tile]: no atomics, no sort, whatever the density.
-    uint32_t *tile_count;      // matches per tile (NULL: not recorded; with dense == NULL the old direct path is taken)
-    uint32_t *dense;
+    // Three flag words (one pointer: every pointer here costs two scalar registers around the walk): [0] a position
+    // bucket is full; [1] a workgroup gave up waiting for its slot reservation (finish_parked) -- order_kernel hands
+    // it to the host, bmx_search_device_finish returns BMX_ERR_HIP; [2] a tile was dense (below)
+    uint32_t *bucket_overflow;
+    // Dense results (more matches in a tile than its workgroup can park in LDS): the scan then only COUNTS and
+    // raises bucket_overflow[2]; bmx_search_device_finish runs the FILL pass -- scan_kernel MODE 10 counts the
+    // matches of every tile into tile_count[], their exclusive scan is tile_base[], scan_kernel MODE 9 writes
+    // every tile's matches in ascending order at tile_base[tile]: no atomics, no sort, whatever the density.
+    uint32_t *tile_count;      // fill pass only
     const uint64_t *tile_base; // fill pass only
+    uint32_t dense_enabled;    // 0: a full parking buffer sends the rest of its tile the direct way (global atomics)
     uint32_t bucket_shift;
     // Several patterns in one pass (bmx_search_device_multi; K == 0: the ordinary search).  `multi` is a blob of
     // multi_bytes bytes, per pattern [bad: 256 x u16 | good: m x u16, padded to 16 B | pattern, padded to 16 B] at
@@ -142,7 +143,7 @@ struct LdsTables {
     lds_u32 *wsum;        // 32 words: per-wave totals of the workgroup scans (count-only mode, fill pass)
     // where a walker's matches go: 0 = the parking buffer (the scan), 1 = nowhere, this lane only counts them
     // (a workgroup that met a dense tile; first half of the fill pass), 2 = out[write_at++] (second half of the fill pass)
-    mutable uint32_t sink; // (a lane of the scan switches itself to 1 the moment it finds the parking buffer full)
+    uint32_t sink;
     mutable uint32_t lane_cnt;
     mutable uint64_t write_at;
     uint32_t m;
@@ -189,12 +190,10 @@ __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &t
             return;
         }
         // The buffer is full: this tile is dense.  Its matches have all been COUNTED (the counter above), which
-        // is what the fill pass needs; the workgroup finds out when it collects the tile (scan_kernel).  The
-        // lanes that got here count the rest of their share privately: no more LDS atomics for them.
-        if (a.dense != nullptr) {
-            tb.sink = 1;
-            return;
-        }
+        // is all the scan has to know; the workgroup finds out when it collects the tile and only counts from
+        // there on (scan_kernel).  (Letting each lane switch to private counting right here was measured: the
+        // per-lane state costs the ordinary scan 1.5 %.)
+        if (a.dense_enabled != 0) return;
     }
     // no parking buffer, or a kernel without a fill pass: the direct way, one global atomic per wave and event
     emit_hit(a, astart - a.first, astart + a.out_bias, tb.stage_cap == 0, tb.pat_id);
@@ -232,7 +231,7 @@ __device__ __forceinline__ void finish_parked(const ScanArgs &a, const LdsTables
         }
     }
     if (gave_up) {
-        *a.err = 1u;
+        a.bucket_overflow[1] = 1u;
         return;
     }
     if (a.out == nullptr) return;

@@ -32,8 +32,9 @@
 
 namespace bmx {
 
-// MODE 9: the FILL pass for dense results (see scan_body): every tile walked twice, matches written in ascending
-// order at tile_base[tile] + (exclusive scan of the lanes' counts).
+// MODE 10 / 9: the FILL pass for dense results (see scan_body), two launches: count the matches of every tile; then --
+// after an exclusive scan of those counts -- write every tile's matches in ascending order at tile_base[tile] +
+// (exclusive scan of the lanes' counts), each tile walked twice.
 // AUX: cache-policy bits of the DMA (0 default, 2 = nt: the text is read once).
 // MODE 0 is the product; MODE 1 (DMA only, no walkers) and MODE 2 (walkers only:
 // each workgroup loads its first two tiles and keeps re-walking them) exist for
@@ -145,7 +146,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         const uint32_t before = g == 0 ? 0u : g == 1 ? s0 : g == 2 ? s0 + s1 : s0 + s1 + s2; // per lane of a four-wave group
         seg_lo = 256u * before + ((wave & 3u) * 64 + lane) * seg_len;
     }
-    uint64_t t = a.tile_begin + blockIdx.x, t_prev = 0;
+    const bool dense_mode = a.dense_enabled != 0 && tb.stage_cap != 0; // lanes may switch to counting (dense tiles)
+    bool wg_dense = false; // wave-uniform: this workgroup has met a dense tile and only counts from there on
+    unsigned long long dense_total = 0; // ... and what it has counted in such tiles
+    uint64_t t = a.tile_begin + blockIdx.x;
     uint32_t it = 0; // tiles walked so far by this workgroup
     uint32_t seen[2] = {0, 0}; // the parking buffers' counts as of their last collection
     auto park_buf = [&](uint32_t p) { return tb.stage_area + p * tb.stage_cap; };
@@ -167,7 +171,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     const unsigned long long st_t0 = MODE == 8 ? __builtin_amdgcn_s_memtime() : st_prev; // MODE 8: the two clock stamps only
     const unsigned long long st_r0 = MODE == 5 || MODE == 8 ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-    for (uint64_t t_next = 0; t < a.tile_end; t_prev = t, t = t_next) {
+    for (; t < a.tile_end; t += gridDim.x) {
         // (A) this tile's DMA has landed for every wave, and every wave has
         //     finished walking the other buffer, which is refilled next.
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
@@ -206,19 +210,17 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                 const uint32_t now = __builtin_amdgcn_readfirstlane(parked_now);
                 const uint32_t n_true = now - seen[pp]; // every match of that tile was counted, parked or not
                 seen[pp] = now;
-                if (a.dense != nullptr && (tb.sink == 1 || n_true > tb.stage_cap)) {
+                if (dense_mode && (wg_dense || n_true > tb.stage_cap)) { // (wave-uniform: tb.sink is a per-lane state)
                     // a dense tile: nothing of it is stored -- the fill pass will write the whole list -- and from here
-                    // on this workgroup only counts (per lane, one LDS add per wave and tile instead of one per event)
-                    if (tid == 0) {
-                        *a.dense = 1u;
-                        if (n_true != 0) (void)__hip_atomic_fetch_add(a.count, (unsigned long long)n_true, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                    // on this workgroup only counts (per lane, one LDS add per wave and tile instead of one per event);
+                    // the count goes to the device counter when the workgroup is done (no global access here)
+                    dense_total += n_true;
                     tb.sink = 1;
+                    wg_dense = true;
                 } else {
                     prev_n = n_true < tb.stage_cap ? n_true : tb.stage_cap;
                     if (prev_n != 0 && tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
                 }
-                if (tid == 0 && a.tile_count != nullptr) a.tile_count[t_prev - a.tile_begin] = n_true;
             }
             tb.stage = park_buf(it & 1u);
             tb.stage_cnt = park_cnt(it & 1u);
@@ -284,7 +286,21 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             }
         };
         auto wave_sum = [&](uint32_t v) -> uint32_t { return __builtin_amdgcn_readlane(wave_inclusive_scan(v), 63); };
-        if constexpr (MODE == 9) {
+        if constexpr (MODE == 10) {
+            // first half of the FILL pass: how many matches each tile holds (their exclusive scan tells the second
+            // half, MODE 9, where every tile's matches go)
+            tb.sink = 1;
+            tb.lane_cnt = 0;
+            walk_tile();
+            const uint32_t c = wave_sum(tb.lane_cnt);
+            if (lane == 0) tb.wsum[wave] = c;
+            __syncthreads(); // (the next tile's top barrier separates these reads from the next writes)
+            if (tid == 0) {
+                uint32_t n_tile = 0;
+                for (uint32_t w = 0; w < (uint32_t)NW; ++w) n_tile += tb.wsum[w];
+                a.tile_count[t - a.tile_begin] = n_tile;
+            }
+        } else if constexpr (MODE == 9) {
             // FILL pass (bmx_search_device_finish, dense results): count this lane's matches, take the exclusive
             // scan over the workgroup's lanes -- lanes own ascending pieces of the tile, so lane order is position
             // order --, then walk again and write each match at its final place.  No atomics, no sort.
@@ -309,7 +325,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             }
         } else {
             walk_tile();
-            if (a.dense != nullptr && tb.stage_cap != 0) { // lanes in count-only mode (dense tiles): one LDS add per wave and tile
+            if (wg_dense) { // count-only mode (after a dense tile): one LDS add per wave and tile
                 const uint32_t c = wave_sum(tb.lane_cnt);
                 tb.lane_cnt = 0;
                 if (lane == 0 && c != 0) {
@@ -320,7 +336,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         }
         if (issue_now && issue_late) issue_tile(tn, cur ? buf0 : buf1);
         if (prev_n != 0) // the previous tile's matches: reserved before this tile's DMA, stored now
-            finish_parked<BLOCK>(a, tb, t_prev * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
+            finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
         ++it;
         if (MODE == 5) {
             const unsigned long long x = stamp();
@@ -329,27 +345,27 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             ++st_n;
         }
         cur ^= 1;
-        t_next = tn;
     }
     if (MODE != 1 && tb.stage_cap != 0 && it != 0) { // what the last tile left parked
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         const uint32_t pp = (it & 1u) ^ 1u;
         const uint32_t n_true = __builtin_amdgcn_readfirstlane(*park_cnt(pp)) - seen[pp];
-        if (tid == 0 && a.tile_count != nullptr) a.tile_count[t_prev - a.tile_begin] = n_true;
-        if (a.dense != nullptr && (tb.sink == 1 || n_true > tb.stage_cap)) {
-            if (tid == 0) {
-                *a.dense = 1u;
-                if (n_true != 0) (void)__hip_atomic_fetch_add(a.count, (unsigned long long)n_true, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        if (dense_mode && (wg_dense || n_true > tb.stage_cap)) {
+            dense_total += n_true;
+            wg_dense = true;
         } else {
             const uint32_t prev_n = n_true < tb.stage_cap ? n_true : tb.stage_cap;
             if (prev_n != 0) {
                 unsigned long long reserved = 0;
                 if (tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
-                finish_parked<BLOCK>(a, tb, t_prev * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
+                finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
             }
         }
+    }
+    if (wg_dense && tid == 0) { // tell bmx_search_device_finish, and add what the dense tiles held to the total
+        a.bucket_overflow[2] = 1u;
+        (void)__hip_atomic_fetch_add(a.count, dense_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if ((MODE == 5 || MODE == 8) && a.stamps != nullptr && lane == 0) {
         unsigned long long *o = a.stamps + ((uint64_t)blockIdx.x * (BLOCK / 64) + wave) * 8;

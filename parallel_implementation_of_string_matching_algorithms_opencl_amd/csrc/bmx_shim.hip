@@ -79,6 +79,8 @@ struct Variant {
     // direct way (global atomics) and bmx_search_device_finish sorts
     void (*fill)(const bmx::ScanArgs);
     void (*fill_short)(const bmx::ScanArgs);
+    void (*fill_count)(const bmx::ScanArgs); // the fill pass's first launch (tile counts)
+    void (*fill_count_short)(const bmx::ScanArgs);
 };
 
 // The slot numbers are stable (tools/ and the notes in DESIGN.md refer to them), but the PRODUCT library
@@ -88,7 +90,7 @@ struct Variant {
 // only in libbmx_exp.so, the same sources compiled with -DBMX_EXPERIMENTS for tools/ (BMX_LIB=exp).
 // bmx_set_variant() refuses a slot that is not built: no caller of the shipped C ABI can select a kernel
 // that returns a wrong match list (tests/test_gpu_parity.py::test_product_library_accepts_only_its_variants).
-#define BMX_ABSENT {0, 0, 0, 0, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr}
+#define BMX_ABSENT {0, 0, 0, 0, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
 #ifdef BMX_EXPERIMENTS
 #define BMX_EXP(...) __VA_ARGS__
 #else
@@ -100,19 +102,21 @@ struct Variant {
 #define BMX_TILE_G(B, S, AUX, MODE, W, L, SI, G) \
     {0, B, S, 2, L, SI, (MODE) == 5 || (MODE) == 8, (W) == 3 || (W) == 10, \
      (W) == 3 || (W) == 7 || (W) == 9 ? 4 : ((W) == 8 || (W) == 10 ? 8 : 0), \
-     bmx::scan_kernel<B, S, AUX, MODE, W, L, SI, G>, bmx::scan_kernel<B, S, AUX, MODE, 6, L, SI, G>, nullptr, nullptr}
+     bmx::scan_kernel<B, S, AUX, MODE, W, L, SI, G>, bmx::scan_kernel<B, S, AUX, MODE, 6, L, SI, G>, nullptr, nullptr, nullptr, nullptr}
 // a product geometry: with the fill pass for dense results (byte-wise walker / short-pattern walker on the same tiles)
 #define BMX_TILE_F(B, S, AUX, W) \
     {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 3 ? 4 : ((W) == 10 ? 8 : 0), bmx::scan_kernel<B, S, AUX, 0, W>, \
-     bmx::scan_kernel<B, S, AUX, 0, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>}
+     bmx::scan_kernel<B, S, AUX, 0, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>, \
+     bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>}
 #define BMX_TILE_W32(B, S, AUX, MODE, W) /* 32 waves per CU: the 80-SGPR build */ \
     {0, B, S, 2, 0, 0, (MODE) == 5, (W) == 3, (W) == 3 ? 4 : 0, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, MODE, 6, 0>, \
-     (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 0> : nullptr, (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 6> : nullptr}
+     (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 0> : nullptr, (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 6> : nullptr, \
+     (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 10, 0> : nullptr, (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 10, 6> : nullptr}
 #define BMX_RING(B, S, AUX, SKIP, MODE) BMX_RING_P(B, S, AUX, (SKIP) ? 2 : 0, MODE, 0)
 #define BMX_RING_P(B, S, AUX, W, MODE, P) \
-    {2, B, S, 3, 0, 0, (MODE) == 5, (W) == 10, (W) == 10 ? 8 : 0, bmx::scan_ring_kernel<B, S, AUX, W, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, 0, MODE, P>, nullptr, nullptr}
+    {2, B, S, 3, 0, 0, (MODE) == 5, (W) == 10, (W) == 10 ? 8 : 0, bmx::scan_ring_kernel<B, S, AUX, W, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, 0, MODE, P>, nullptr, nullptr, nullptr, nullptr}
 #define BMX_WAVE(WV, S, AUX, MODE, D, NB)                                                      \
-    {1, (WV) * 64, S, NB, 0, 0, false, false, 0, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, nullptr, nullptr}
+    {1, (WV) * 64, S, NB, 0, 0, false, false, 0, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, nullptr, nullptr, nullptr, nullptr}
 const Variant g_variants[] = {
     BMX_TILE_F(1024, 68, 2, 0),                  // 0: PRODUCT -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
                                                  //    (the automatic choice for m < 4 and for dense small-alphabet results)
@@ -548,9 +552,8 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         a.bucket_cnt = ctx->d_bucket_cnt;
         a.bucket_store = ctx->d_bucket_store;
         a.bucket_overflow = ctx->d_overflow;
-        a.err = ctx->d_overflow + 1;
         a.tile_count = nullptr;
-        a.dense = nullptr;
+        a.dense_enabled = 0;
         a.tile_base = nullptr;
         a.multi = nullptr;
         a.multi_bytes = a.K = a.bucket_stride = 0;
@@ -580,8 +583,9 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
 
         // dense results: the scan counts per tile, bmx_search_device_finish runs the fill pass of this geometry
         auto fill = m >= 4 ? v.fill : v.fill_short;
+        if (getenv("BMX_NO_DENSE")) fill = nullptr; // (tools/: A/B runs)
         ctx->last_fillable = false;
-        if (fill != nullptr && a.stage_cap != 0) a.dense = ctx->d_overflow + 2; // (count-only calls too: dense tiles are just counted)
+        if (fill != nullptr && a.stage_cap != 0) a.dense_enabled = 1; // (count-only calls too: dense tiles are just counted)
         if (fill != nullptr && a.stage_cap != 0 && out != nullptr) {
             const uint64_t n_tiles = a.tile_end - a.tile_begin;
             if (ctx->tile_cap < n_tiles) {
@@ -594,7 +598,6 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
                 HIPCHK(hipMalloc(&ctx->d_tile_base, n_tiles * sizeof(uint64_t)));
                 ctx->tile_cap = n_tiles;
             }
-            a.tile_count = ctx->d_tile_count;
             ctx->last_fillable = true;
         }
         const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
@@ -689,17 +692,21 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
         auto fill = ctx->last_m >= 4 ? v.fill : v.fill_short;
         bmx::ScanArgs a = ctx->last_args;
         const uint64_t n_tiles = a.tile_end - a.tile_begin;
-        hipLaunchKernelGGL(bmx::tile_scan_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, ctx->d_tile_count, n_tiles,
-                           ctx->d_tile_base);
-        HIPCHK(hipGetLastError());
+        auto fill_count = ctx->last_m >= 4 ? v.fill_count : v.fill_count_short;
         a.out = d_match_positions;
         a.cap = capacity;
         a.stage_cap = 0;
         a.tile_base = ctx->d_tile_base;
-        a.tile_count = nullptr;
-        a.dense = nullptr;
+        a.tile_count = ctx->d_tile_count;
+        a.dense_enabled = 0;
         const uint32_t lds = lds_bytes_with(v, ctx->last_m, 0);
+        HIPCHK(hipFuncSetAttribute((const void *)fill_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void *)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fill_count, dim3(ctx->last_grid), dim3(v.block), lds, stream, a);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(bmx::tile_scan_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, ctx->d_tile_count, n_tiles,
+                           ctx->d_tile_base);
+        HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(fill, dim3(ctx->last_grid), dim3(v.block), lds, stream, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
@@ -735,7 +742,7 @@ int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_o
 namespace {
 constexpr uint32_t MULTI_BLOB_MAX = bmx::MAX_MULTI * (512 + 2 * ((BMX_MAX_PATTERN + 7) & ~7) + BMX_MAX_PATTERN + 32);
 const auto g_multi_kernel = bmx::scan_kernel<1024, 68, 2, 0, 20>;
-const Variant g_multi_variant = {0, 1024, 68, 2, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr};
+const Variant g_multi_variant = {0, 1024, 68, 2, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 } // namespace
 
 int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own, uint64_t base_offset,
@@ -830,9 +837,8 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     a.bucket_cnt = ctx->d_bucket_cnt;
     a.bucket_store = ctx->d_bucket_store;
     a.bucket_overflow = ctx->d_overflow;
-    a.err = ctx->d_overflow + 1;
     a.tile_count = nullptr;
-    a.dense = nullptr; // dense tiles take the direct path, raise the overflow flag and send the call the exact way
+    a.dense_enabled = 0; // dense tiles take the direct path, raise the overflow flag and send the call the exact way
     a.tile_base = nullptr;
     a.stamps = nullptr;
     a.m = (uint32_t)m_max;

@@ -28,6 +28,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libbmx.so")
 # timing-only kernels whose match lists are not valid).  Tests, bench.py and smoke() never set it.
 if os.environ.get("BMX_LIB") == "exp":
     LIB_PATH = os.path.join(_HERE, "lib", "libbmx_exp.so")
+elif os.environ.get("BMX_LIB"):  # an explicit path: A/B runs of an older build on the same box (tools/ only)
+    LIB_PATH = os.environ["BMX_LIB"]
 
 MAX_PATTERN = 512
 MAX_MULTI = 8
@@ -110,7 +112,10 @@ def lib():
                 f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C parallel_implementation_of_string_matching_algorithms_opencl_amd/csrc`")
         L = C.CDLL(LIB_PATH)
+        older_build = os.environ.get("BMX_LIB", "exp") != "exp"  # (tools/ A/B runs: an older build may lack newer entry points)
         for name, res, args in SYMBOLS:
+            if older_build and not hasattr(L, name):
+                continue
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
