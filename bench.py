@@ -235,6 +235,7 @@ def bench_suffix_array(args, dev, local_rank):
             "warmup": min(args.warmup, 3), "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "sa2m", "chars": n, "period": int(para.size), "rounds": ctx.last_suffix_array_rounds(),
+                       "rounds_in_lds": ctx.last_suffix_array_lds_rounds(),
                        "device_ms": round(float(np.mean(dev_ms)), 3)}, "roofline": None}
     if not args.no_cpu_baseline:
         import oracle  # reported baseline + checker only

@@ -248,6 +248,8 @@ int bmx_suffix_array_device(bmx_ctx *ctx, const void *d_text, uint64_t n, int32_
 /* Device time (ms) and number of doubling rounds of the last call. */
 float bmx_last_suffix_array_ms(bmx_ctx *ctx);
 int bmx_last_suffix_array_rounds(bmx_ctx *ctx);
+/* ... of which done by the one-kernel LDS path (every group of tied suffixes fitted a workgroup's window). */
+int bmx_last_suffix_array_lds_rounds(bmx_ctx *ctx);
 
 /* ---- synthetic corpus, generated in HBM ---------------------- */
 

@@ -213,7 +213,7 @@ struct bmx_ctx {
     float sa_last_ms = -1.0f;
     void *sa_ws = nullptr; // suffix-array workspace, kept between calls while it is small
     size_t sa_ws_bytes = 0;
-    int sa_last_rounds = 0;
+    int sa_last_rounds = 0, sa_last_lds_rounds = 0;
     int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
     unsigned long long *d_count = nullptr; // live match counter; re-armed by order_kernel
     uint32_t *d_tile_count = nullptr;      // matches per tile of the last scan (dense results: input of the fill pass)
@@ -1216,6 +1216,8 @@ int bmx_suffix_array_device(bmx_ctx *ctx, const void *d_text, uint64_t n, int32_
     const int rc = bmx_internal_suffix_array((const uint8_t *)d_text, (uint32_t)n, d_sa, (hipStream_t)stream_v,
                                              &ctx->sa_last_ms, &ctx->sa_last_rounds, &ctx->sa_ws, &ctx->sa_ws_bytes, g_err,
                                              sizeof g_err);
+    ctx->sa_last_lds_rounds = ctx->sa_last_rounds >> 16;
+    ctx->sa_last_rounds &= 0xffff;
     if (ctx->sa_ws_bytes > ED_BAND_WS_KEEP) { // a large one is not kept
         (void)hipFree(ctx->sa_ws);
         ctx->sa_ws = nullptr;
@@ -1253,6 +1255,7 @@ int bmx_suffix_array(bmx_ctx *ctx_in, const char *text, uint64_t n, int32_t *sa_
 
 float bmx_last_suffix_array_ms(bmx_ctx *ctx) { return ctx ? ctx->sa_last_ms : -1.0f; }
 int bmx_last_suffix_array_rounds(bmx_ctx *ctx) { return ctx ? ctx->sa_last_rounds : 0; }
+int bmx_last_suffix_array_lds_rounds(bmx_ctx *ctx) { return ctx ? ctx->sa_last_lds_rounds : 0; }
 
 int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out)
 {

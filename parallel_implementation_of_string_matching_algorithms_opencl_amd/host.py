@@ -88,6 +88,7 @@ SYMBOLS = [
     ("bmx_suffix_array_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     ("bmx_last_suffix_array_ms", C.c_float, [C.c_void_p]),
     ("bmx_last_suffix_array_rounds", C.c_int, [C.c_void_p]),
+    ("bmx_last_suffix_array_lds_rounds", C.c_int, [C.c_void_p]),
     ("bmx_gen_text_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]),
     ("bmx_plant_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int32, _u64p,
                                    C.c_uint64, C.c_void_p]),
@@ -406,6 +407,9 @@ class Context:
 
     def last_suffix_array_rounds(self) -> int:
         return int(lib().bmx_last_suffix_array_rounds(self._h))
+
+    def last_suffix_array_lds_rounds(self) -> int:
+        return int(lib().bmx_last_suffix_array_lds_rounds(self._h))
 
     # -- synthetic corpus in HBM ------------------------------------------
     def gen_text(self, d_dst, start: int, seed: int, kind: int = 0, length: Optional[int] = None):

@@ -109,3 +109,22 @@ def test_gpu_2MiB_random_lowercase_is_sorted(ctx):
     rows = np.arange(n - 1)
     assert neq.any(axis=1).all()
     assert (a[rows, first] < b[rows, first]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_groups_around_the_lds_window(ctx, port):
+    """Rounds run in ONE kernel when every group of tied suffixes fits a workgroup's LDS window (8192 entries, of which
+    a workgroup owns the first 3072 .. 8128 depending on the longest group), through the library sort otherwise.  Periodic
+    texts make groups of n / period entries that stay tied until the last rounds: sizes just below and above every limit,
+    plus texts whose last group ends exactly at a window's end, against the oracle."""
+    rng = np.random.default_rng(77)
+    for n, period in ((150_000, 50), (150_000, 37), (150_000, 29), (150_000, 18), (150_000, 17), (8192 * 9, 23), (8192 * 9, 9),
+                      (3072 * 20, 11), (200_003, 41), (65_536, 8), (100_000, 1), (100_000, 2)):
+        para = (rng.integers(0, 26, period) + 97).astype(np.uint8)
+        x = np.tile(para, n // period + 1)[:n].copy()
+        sa = ctx.suffix_array(x)
+        assert np.array_equal(sa, port.suffix_array(x)), (n, period, ctx.last_suffix_array_rounds(), ctx.last_suffix_array_lds_rounds())
+    # a random text: groups shrink to single entries after two or three rounds, every later round is the LDS kernel's
+    x = (rng.integers(0, 4, 300_000) + 97).astype(np.uint8)
+    assert np.array_equal(ctx.suffix_array(x), port.suffix_array(x))
+    assert ctx.last_suffix_array_lds_rounds() >= 1
