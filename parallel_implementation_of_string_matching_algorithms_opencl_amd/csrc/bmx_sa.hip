@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
+#include <vector>
 
 #include "bmx.h"
 
@@ -260,9 +261,16 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
         const uint64_t p = (uint64_t)base + slot;
         const bool ends_here = slot > F && (nh[q] || p == n);
         if (!ends_here) continue;
+        const uint64_t kb = q > 0 ? kq[q - 1] : kprev; // the entry before: the last one of the group that ends here
         const int ph = q > 0 ? ngh[q - 1] : -1;
-        const int prev_head = ph >= 0 ? ph : nbefore; // head of the group that ends at slot - 1
-        if (prev_head >= 0 && (uint32_t)prev_head < SEG_C) longest = max(longest, slot - (uint32_t)prev_head);
+        const int prev_head = ph >= 0 ? ph : nbefore; // ... and that group's (new) head
+        // this workgroup's to measure if the OLD group it came out of begins among the owned slots (its new head may not)
+        if (prev_head >= 0 && kb != ~0ull && (uint32_t)(kb >> 45) < SEG_C) longest = max(longest, slot - (uint32_t)prev_head);
+    }
+    if (tid == SEG_T - 1) { // a group that ends exactly with the window has no "next head" inside it
+        const uint64_t k = kq[SEG_PER - 1];
+        const int hd = ngh[SEG_PER - 1] >= 0 ? ngh[SEG_PER - 1] : nbefore;
+        if (k != ~0ull && SEG_W - 1 >= F && hd >= 0 && (uint32_t)(k >> 45) < SEG_C) longest = max(longest, SEG_W - (uint32_t)hd);
     }
     if (longest != 0) atomicMax(&max_len, longest);
     uint32_t heads = 0;
@@ -311,7 +319,7 @@ int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, 
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_keys = up((size_t)n * sizeof(uint64_t)), b_u32 = up((size_t)n * sizeof(uint32_t));
     const size_t b_tmp = up(tmp_sort > tmp_scan ? tmp_sort : tmp_scan);
-    const size_t b_cnt = 512; // four counters per round of the LDS path
+    const size_t b_cnt = 1024; // four counters per round of the LDS path
     const size_t need = 2 * b_keys + 5 * b_u32 + b_tmp + b_cnt;
     if (ok() && *ws_bytes < need) {
         if (*ws) (void)hipFree(*ws);
@@ -385,6 +393,21 @@ int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, 
             uint32_t hc[3] = {0, 0, 0};
             if (ok()) e = hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, stream);
             if (ok()) e = hipStreamSynchronize(stream);
+            if (getenv("BMX_SA_DEBUG")) {
+                fprintf(stderr, "sa: round %d (h %u, own %u): groups %u too_big %u longest %u\n", rounds, h, own, hc[0], hc[1], hc[2]);
+                if (hc[1] == 0) { // the true longest run of the flags this round wrote
+                    std::vector<uint32_t> f(n);
+                    (void)hipMemcpy(f.data(), flags_alt, (size_t)n * 4, hipMemcpyDeviceToHost);
+                    uint32_t best = 0, best_at = 0, start = 0;
+                    for (uint32_t i = 1; i <= n; ++i)
+                        if (i == n || f[i] != 0) {
+                            if (i - start > best) best = i - start, best_at = start;
+                            start = i;
+                        }
+                    fprintf(stderr, "sa:   true longest %u at position %u (window %u, slot %u; ends at slot %u)\n", best, best_at, best_at / own,
+                            best_at % own, best_at % own + best);
+                }
+            }
             if (ok() && hc[1] == 0) {
                 std::swap(idx_cur, idx_alt);
                 std::swap(flags_cur, flags_alt);
@@ -396,6 +419,58 @@ int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, 
             }
         }
         ++rounds;
+        if (done && ok() && getenv("BMX_SA_NO_PIPELINE") == nullptr) {
+            // From here on every round is an LDS round (groups only shrink): the rounds are queued back to back and the
+            // host looks at a round's counters -- copied into pinned memory behind the kernel -- while the NEXT round
+            // already runs, instead of synchronising the stream after every round.  The round that turns out to be one
+            // too many finds nothing tied and copies its input through.
+            static thread_local uint32_t *hp = nullptr; // pinned: 4 words per round
+            if (!hp && hipHostMalloc(&hp, 64 * 4 * sizeof(uint32_t)) != hipSuccess) hp = nullptr;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            if (hp && hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess) {
+                int pending = -1; // a round whose counters are on their way
+                auto look = [&](int r) { // wait for round r's counters (the stream is already busy with round r + 1)
+                    e = hipEventSynchronize(ev[r & 1]);
+                    if (getenv("BMX_SA_DEBUG")) fprintf(stderr, "sa: pipelined round %d: groups %u too_big %u longest %u\n", r, hp[4 * r], hp[4 * r + 1], hp[4 * r + 2]);
+                    if (ok() && hp[4 * r + 1] != 0) e = hipErrorAssert; // a group outgrew its window: cannot happen, groups only split
+                    if (ok()) {
+                        groups = hp[4 * r];
+                        longest_group = hp[4 * r + 2];
+                    }
+                };
+                for (k *= 2; ok() && groups < n && k < 2 * (uint64_t)n && rounds < 30; k *= 2) {
+                    uint32_t *cnt = counters + 4 * rounds;
+                    const uint32_t own = std::max(1024u, std::min(SEG_W - 64u, SEG_W - longest_group));
+                    const uint32_t nblk = (uint32_t)(((uint64_t)n + own - 1) / own);
+                    if (getenv("BMX_SA_DEBUG")) fprintf(stderr, "sa: queue round %d (h %u, own %u, longest known %u)\n", rounds, (uint32_t)(k / 2), own, longest_group);
+                    hipLaunchKernelGGL(sa_segsort_kernel, dim3(nblk), dim3(SEG_T), 0, stream, idx_cur, flags_cur, rank_cur, n,
+                                       (uint32_t)(k / 2), own, idx_alt, flags_alt, rank_alt, cnt);
+                    e = hipGetLastError();
+                    if (ok()) e = hipMemcpyAsync(hp + 4 * rounds, cnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+                    if (ok()) e = hipEventRecord(ev[rounds & 1], stream);
+                    std::swap(idx_cur, idx_alt);
+                    std::swap(flags_cur, flags_alt);
+                    std::swap(rank_cur, rank_alt);
+                    const int mine = rounds;
+                    ++rounds;
+                    ++lds_rounds;
+                    if (pending >= 0 && ok()) {
+                        look(pending);
+                        if (ok() && groups == n) { // the round before this one finished the job: this one was one too many
+                            --rounds;
+                            --lds_rounds;
+                            pending = -1;
+                            break;
+                        }
+                    }
+                    pending = mine;
+                }
+                if (pending >= 0 && ok()) look(pending);
+            }
+            if (ev[0]) (void)hipEventDestroy(ev[0]);
+            if (ev[1]) (void)hipEventDestroy(ev[1]);
+            if (hp) break; // (without pinned memory: the synchronous loop goes on)
+        }
         if (!done && ok()) {
             if (rank_cur != rank) { // (cannot happen: groups only shrink.  Kept correct all the same.)
                 e = hipMemcpyAsync(rank, rank_cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
