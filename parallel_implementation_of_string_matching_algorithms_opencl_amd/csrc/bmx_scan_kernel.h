@@ -9,7 +9,8 @@
 //
 //   HBM --(global_load_lds_dwordx4, 16 B/lane, no VGPR round trip)--> LDS tile
 //   LDS tile --(one Boyer-Moore walker per lane over its own SEG-byte segment)--> hits
-//   hits --(wave __ballot / popcount ranks, one atomic per wave per event)--> HBM list
+//   hits --(wave __ballot / popcount ranks into an LDS parking buffer; ONE global atomic per workgroup and tile,
+//           deferred by a tile; dense tiles are only counted and written by the fill pass)--> HBM list
 //
 //  * A workgroup owns tiles t = blockIdx, blockIdx + grid, ...; tile t is the
 //    TILE = BLOCK*SEG window starts [t*TILE, (t+1)*TILE) and needs the bytes

@@ -20,8 +20,8 @@
 //     (border of length b  <=>  suff[b-1] == b), and stores s = m-b. (:175-183)
 //   * Otherwise m.                                                  (:185-189)
 //
-// tests/test_tables.py checks the result against the reference build for
-// thousands of patterns and against the known-answer tables of SURVEY.md s4.
+// tests/test_abi_and_tables.py checks the result against the reference build for
+// thousands of patterns, tests/test_oracle_golden.py against the known-answer tables of SURVEY.md s4.
 #include "bmx.h"
 
 #include <vector>
