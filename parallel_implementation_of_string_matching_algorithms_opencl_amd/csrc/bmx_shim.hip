@@ -193,6 +193,16 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 0, 0, 0, 4)),   // 65: 44 / 60 / 92 / 108 (control: the wrong way round)
     BMX_EXP(BMX_TILE_G(1024, 76, 2, 5, 0, 0, 0, 1)),   // 66: stamps of 62
     BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 10, 0, 0, 2)),  // 67: 8-gram walker, graded 100 / 84 / 68 / 52
+    // DMA only with other cache-policy bits of global_load_lds (aux: 1 = sc0, 2 = nt, 16 = sc1)
+    BMX_EXP(BMX_TILE(1024, 76, 0, 1, 0)),              // 68
+    BMX_EXP(BMX_TILE(1024, 76, 1, 1, 0)),              // 69
+    BMX_EXP(BMX_TILE(1024, 76, 3, 1, 0)),              // 70
+    BMX_EXP(BMX_TILE(1024, 76, 16, 1, 0)),             // 71
+    BMX_EXP(BMX_TILE(1024, 76, 17, 1, 0)),             // 72
+    BMX_EXP(BMX_TILE(1024, 76, 18, 1, 0)),             // 73
+    BMX_EXP(BMX_TILE(1024, 76, 19, 1, 0)),             // 74
+    BMX_EXP(BMX_TILE(1024, 76, 3, 0, 0)),              // 75: variant 29 with sc0 nt
+    BMX_EXP(BMX_TILE(1024, 76, 18, 0, 0)),             // 76: variant 29 with sc1 nt
 };
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr uint32_t LDS_PER_CU = 160 * 1024;

@@ -99,3 +99,26 @@ def test_merge_of_shard_lists_is_sorted(port):
             loc = port.search(text[start:start + length], spec.pattern())
             lists.append(loc[loc < n_own] + np.uint64(start))
         assert np.array_equal(shard.merge_shard_lists(lists), want)
+
+
+def test_bench_parent_fails_with_its_ranks_and_does_not_hang():
+    """`python bench.py --gpus 2` launched plainly is only a parent that starts the ranks (bench.self_launch).  On
+    a machine without a GPU the ranks fail at once: the parent must come back with a non-zero code -- quickly,
+    without a JSON line, and without having imported torch itself."""
+    import os
+    import subprocess
+    import sys
+    import time
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU suite runs the real thing (tests/test_gpu_sharded.py)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 240
