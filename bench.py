@@ -270,7 +270,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearse else dev  # where the small control collectives live
+    saved_stdout = None
     if multi:
+        # RCCL prints a version banner on STDOUT when its first communicator comes up: everything a rank writes to
+        # file descriptor 1 before the JSON line goes to stderr instead, so that stdout carries that ONE line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
@@ -280,6 +286,16 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    def restore_stdout():
+        nonlocal saved_stdout
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
+            saved_stdout = None
+
+    if args.workload in ("ed64k", "sa2m"):
+        restore_stdout()
     if args.workload == "ed64k":  # BASELINE config 5 (secondary: the reference's second algorithm)
         return bench_edit_distance(args, dev, local_rank)
     if args.workload == "sa2m":  # the reference's third program at its largest input size (2 MiB)
@@ -428,6 +444,7 @@ def main():
         line["parity"]["host_entry_point_exact"] = bool(np.array_equal(got, result))
 
     ok = planted_ok and all(v is not False for v in line["parity"].values())
+    restore_stdout()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if multi:
