@@ -32,17 +32,35 @@
 
 #include "bmx.h"
 
+#ifndef SA_EXP
+#define SA_EXP 0 // (timing builds, never shipped: 1 = no sort, 8 = phase times of sa_segsort_kernel on stderr)
+#endif
+
 namespace {
 
 __device__ __forceinline__ uint32_t char_rank(uint8_t c) { return (uint8_t)(c + 128u); } // signed-char order, 0..255
 constexpr uint32_t END_RANK_ROUND0 = 96u + 128u; // "past the end" == character 96 in the first round
 
+// Key of the first sort: the suffix's first FOUR symbols, i.e. the reference's first-two-characters sort (:106-113)
+// and its first doubling round (k = 4) in one.  The reference builds a suffix's symbols out of pairs (i, i + 1),
+// (i + 2, i + 3), ...: a pair that begins at the last character has '`' (its -1) as second symbol, a pair that begins
+// behind the text is below every pair.  So position n reads '`' for the suffixes with n - 1 - i even and "nothing" for
+// the others; "nothing" is a 0 byte here and the number of real symbols (low 3 bits) puts it below a real 0x80.
+constexpr int INIT_KEY_BITS = 35;
 __global__ void sa_init_keys(const uint8_t *text, uint32_t n, uint64_t *keys, uint32_t *idx)
 {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t r0 = char_rank(text[i]);
-        const uint32_t r1 = i + 1 < n ? char_rank(text[i + 1]) : END_RANK_ROUND0;
-        keys[i] = ((uint64_t)r0 << 8) | r1;
+        uint64_t symbols = 0;
+        uint32_t real = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) {
+            const uint64_t pos = (uint64_t)i + t;
+            uint32_t sym = 0;
+            if (pos < n) sym = char_rank(text[pos]), ++real;
+            else if (pos == n && ((n - 1 - i) & 1u) == 0) sym = END_RANK_ROUND0, ++real;
+            symbols = (symbols << 8) | sym;
+        }
+        keys[i] = (symbols << 3) | real;
         idx[i] = i;
     }
 }
@@ -59,10 +77,30 @@ __global__ void sa_build_keys(const uint32_t *rank, uint32_t n, uint32_t h, uint
     }
 }
 
-__global__ void sa_head_flags(const uint64_t *keys_sorted, uint32_t n, uint32_t *flags)
+__global__ void sa_head_flags(const uint64_t *keys_sorted, uint32_t n, uint32_t *flags, uint32_t *group_stats)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) group_stats[0] = 0, group_stats[1] = 0; // (sa_group_longest, later in the stream)
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
         flags[j] = j > 0 && keys_sorted[j] != keys_sorted[j - 1] ? 1u : 0u;
+}
+
+// the longest group of equal keys (the LDS rounds size their windows by it): head positions by group number, then
+// the distances between them
+__global__ void sa_group_heads(const uint32_t *flags, const uint32_t *scanned, uint32_t n, uint32_t *head_pos)
+{
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        if (j == 0 || flags[j] != 0) head_pos[scanned[j]] = j;
+}
+
+__global__ void sa_group_longest(const uint32_t *head_pos, const uint32_t *scanned, uint32_t n, uint32_t *out /* {groups, longest} */)
+{
+    const uint32_t G = scanned[n - 1] + 1u;
+    uint32_t longest = 0;
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x)
+        longest = max(longest, (g + 1 < G ? head_pos[g + 1] : n) - head_pos[g]);
+    for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o));
+    if ((threadIdx.x & 63) == 0 && longest != 0) atomicMax(&out[1], longest);
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = G;
 }
 
 __global__ void sa_scatter_ranks(const uint32_t *idx_sorted, const uint32_t *scanned, uint32_t n, uint32_t *rank)
@@ -90,55 +128,92 @@ __global__ void sa_copy_out(const uint32_t *idx_sorted, uint32_t n, int32_t *sa)
 // two counters.  A group too long for the window raises `too_big`: the host then runs the library path for that
 // round (groups only ever get smaller, so that ends).
 // Ranks here are "position of the group's head + 1" (order-preserving like the dense numbering; 0 = past the end).
-constexpr uint32_t SEG_W = 8192, SEG_C0 = 3072, SEG_T = 1024, SEG_PER = SEG_W / SEG_T; // (SEG_C0: owned entries per window while the longest group is unknown)
+#if SA_EXP & 8
+__device__ unsigned long long sa_dbg[8]; // phase times of sa_segsort_kernel, summed over workgroups (10 ns units), and their number
+#endif
+constexpr uint32_t SEG_W = 8192, SEG_T = 1024, SEG_PER = SEG_W / SEG_T;
 
 // Slot s of the window lives at LDS word s + s / 8: a thread's 8 consecutive slots (and the 8 slots 2^sh apart that the
 // sorting rounds below give it) then fall into different banks instead of 16 lanes onto one.
 __device__ __forceinline__ uint32_t seg_pos(uint32_t s) { return s + (s >> 3); }
 
-// Bitonic sort of the 8192 keys of a window, ascending.  Every round a thread takes the 8 keys whose slots differ
-// only in bits sh+2..sh, applies up to three consecutive steps of the network to them in registers (distances 4, 2,
-// 1 in its own numbering = 4, 2, 1 << sh in slots) and puts them back: 43 rounds = 43 barriers for the 91 steps.
-__device__ __forceinline__ void seg_sort_round(uint64_t *key, uint32_t tid, uint32_t k2, uint32_t sh, uint32_t j_top, uint32_t j_low)
+// Bitonic sort of the 8192 keys of a window, ascending, in the form whose comparators all point the same way: phase
+// p = 1..13 turns sorted runs of 2^(p-1) into sorted runs of 2^p with a MIRROR step (slot s against s ^ (2^p - 1)) and
+// then steps at distances 2^(p-2) ... 1 (s against s ^ distance); the smaller key always goes to the lower slot, so
+// a compare-exchange is one 64-bit compare and four selects.  Phases 1-3 happen in registers before the keys are
+// written (sort8: a thread builds 8 consecutive slots).  From phase 4 on a round = one LDS exchange: a thread takes
+// the 8 keys whose slots differ in bits sh+2..sh and applies up to three consecutive steps (distances 4, 2, 1 << sh)
+// to them in registers.  A round that begins with the mirror step takes, for its upper four registers, the mirror
+// images of the lower four: that set is closed under the following steps too, only its slot order is reversed.
+// 32 rounds = 32 barriers for the 85 steps behind sort8.
+__device__ __forceinline__ void seg_cx(uint64_t &lo, uint64_t &hi)
+{
+    const uint64_t a = lo, b = hi;
+    uint64_t b2 = b;
+    asm("" : "+v"(b2)); // hipcc otherwise reads min(a, b) and max(a, b) into this and compares twice
+    const bool lt = a < b;
+    lo = lt ? a : b2;
+    hi = lt ? b2 : a;
+}
+
+__device__ __forceinline__ void sort8(uint64_t (&r)[8]) // 19 comparators
+{
+    seg_cx(r[0], r[2]), seg_cx(r[1], r[3]), seg_cx(r[4], r[6]), seg_cx(r[5], r[7]);
+    seg_cx(r[0], r[4]), seg_cx(r[1], r[5]), seg_cx(r[2], r[6]), seg_cx(r[3], r[7]);
+    seg_cx(r[0], r[1]), seg_cx(r[2], r[3]), seg_cx(r[4], r[5]), seg_cx(r[6], r[7]);
+    seg_cx(r[2], r[4]), seg_cx(r[3], r[5]);
+    seg_cx(r[1], r[4]), seg_cx(r[3], r[6]);
+    seg_cx(r[1], r[2]), seg_cx(r[3], r[4]), seg_cx(r[5], r[6]);
+}
+
+// STEPS: the top 1, 2 or 3 of the distances 4, 2, 1 << sh; MIRROR: the first of them is the phase's mirror step
+// (low_mask = 2^p - 1).
+template <int STEPS, bool MIRROR>
+__device__ __forceinline__ void seg_sort_round(uint64_t *key, uint32_t tid, uint32_t sh, uint32_t low_mask)
 {
     const uint32_t base = ((tid >> sh) << (sh + 3)) | (tid & ((1u << sh) - 1u));
+    uint32_t pos[8];
     uint64_t r[8];
 #pragma unroll
-    for (uint32_t q = 0; q < 8; ++q) r[q] = key[seg_pos(base | (q << sh))];
+    for (uint32_t q = 0; q < 8; ++q) {
+        const uint32_t s = MIRROR && (q & 4u) ? (base | ((q ^ 4u) << sh)) ^ low_mask : base | (q << sh);
+        pos[q] = seg_pos(s);
+        r[q] = key[pos[q]];
+    }
 #pragma unroll
-    for (uint32_t d = 4; d > 0; d >>= 1) {
-        const uint32_t j = d << sh;
-        if (j > j_top || j < j_low) continue;
+    for (int step = 2; step > 2 - STEPS; --step) {
+        const uint32_t d = 1u << step;
 #pragma unroll
         for (uint32_t q = 0; q < 8; ++q) {
-            if ((q & d) == 0) {
-                const bool up = ((base | (q << sh)) & k2) == 0; // (the partners q and q | d agree in bit k2: d << sh < k2)
-                const uint64_t a = r[q], b = r[q | d];
-                const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
-                r[q] = up ? lo : hi;
-                r[q | d] = up ? hi : lo;
-            }
+            if ((q & d) != 0) continue;
+            if (MIRROR && step < 2 && (q & 4u)) seg_cx(r[q | d], r[q]); // mirror images: register order is the reverse of slot order
+            else seg_cx(r[q], r[q | d]);
         }
     }
 #pragma unroll
-    for (uint32_t q = 0; q < 8; ++q) key[seg_pos(base | (q << sh))] = r[q];
+    for (uint32_t q = 0; q < 8; ++q) key[pos[q]] = r[q];
 }
 
+// the window holds sorted runs of 8 (sort8); phases 4..13
 __device__ __forceinline__ void seg_sort(uint64_t *key, uint32_t tid)
 {
-    for (uint32_t k2 = 2; k2 <= SEG_W; k2 <<= 1) {
-        const uint32_t top = k2 >> 1; // the steps of phase k2: distances top, top / 2, ..., 1
-        // rounds by fixed triples of distances: {4096, 2048, 1024}, {512, 256, 128}, {64, 32, 16}, {8, 4, 2}, {1}
-        // (one copy of the round's code, the triple chosen at run time: five inlined copies need 119 VGPRs, and with
-        // more than 64 only one workgroup fits a CU)
 #pragma unroll 1
-        for (uint32_t c = 0; c < 5; ++c) {
-            const uint32_t sh = c == 4 ? 0u : 10u - 3u * c;
-            const uint32_t low = c == 4 ? 1u : 1u << sh, high = c == 4 ? 1u : 4u << sh;
-            if (top < low) continue; // (uniform)
-            seg_sort_round(key, tid, k2, sh, top < high ? top : high, low);
+    for (uint32_t p = 4; (1u << p) <= SEG_W; ++p) {
+        const uint32_t low_mask = (1u << p) - 1u;
+        uint32_t left = p - 3, a = p - 1; // steps at distances 2^a ... 8 go first, `left` of them
+        const uint32_t c = (left - 1) % 3 + 1;
+        if (c == 1) seg_sort_round<1, true>(key, tid, a - 2, low_mask);
+        else if (c == 2) seg_sort_round<2, true>(key, tid, a - 2, low_mask);
+        else seg_sort_round<3, true>(key, tid, a - 2, low_mask);
+        __syncthreads();
+        a -= c, left -= c;
+#pragma unroll 1
+        for (; left != 0; left -= 3, a -= 3) {
+            seg_sort_round<3, false>(key, tid, a - 2, 0);
             __syncthreads();
         }
+        seg_sort_round<3, false>(key, tid, 0, 0); // distances 4, 2, 1
+        __syncthreads();
     }
 }
 
@@ -171,13 +246,17 @@ __device__ __forceinline__ int block_excl_scan_max(int mine, int *red, uint32_t 
 __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *idx_in, const uint32_t *head_in,
                                                            const uint32_t *rank_old, uint32_t n, uint32_t h, uint32_t SEG_C,
                                                            uint32_t *idx_out, uint32_t *head_out, uint32_t *rank_new,
-                                                           uint32_t *counters)
+                                                           uint32_t *counters, uint32_t *host_out)
 {
     __shared__ uint64_t key[SEG_W + SEG_W / 8]; // (old group's head slot : 13 | second rank : 32 | slot before the sort : 13), at seg_pos(slot)
     __shared__ int red[SEG_T / 64];
     __shared__ uint32_t any_tie, first_head, n_heads, max_len;
     const uint32_t tid = threadIdx.x;
     const uint32_t base = blockIdx.x * SEG_C;
+#if SA_EXP & 8
+    unsigned long long tq[6];
+    tq[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t s0 = tid * SEG_PER; // this thread's 8 consecutive slots
     if (tid == 0) {
         any_tie = 0;
@@ -187,16 +266,34 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
     }
     __syncthreads();
 
+    // The window comes in with lane-contiguous loads and goes through LDS (the key array's place) to the threads that
+    // own 8 consecutive slots each: read as 8 consecutive words per thread, a load instruction touched 64 different
+    // 32-byte pieces and the phase took 23 us of a workgroup's 92.
+    uint32_t *const st_idx = reinterpret_cast<uint32_t *>(key);
+    uint8_t *const st_head = reinterpret_cast<uint8_t *>(key) + SEG_W * sizeof(uint32_t);
+#pragma unroll
+    for (uint32_t q = 0; q < SEG_PER; ++q) {
+        const uint32_t slot = q * SEG_T + tid;
+        const uint64_t p = (uint64_t)base + slot;
+        const bool valid = p < n;
+        st_idx[slot] = valid ? idx_in[p] : 0u;
+        st_head[slot] = valid && (p == 0 || head_in[p] != 0) ? 1 : 0;
+    }
+    __syncthreads();
     uint32_t t[SEG_PER];
     bool hf[SEG_PER];
     int gh[SEG_PER]; // slot of the head of the slot's group (-1: the group began before the window)
     int last = -1, first = -1;
+    {
+        const uint4 ta = *reinterpret_cast<const uint4 *>(st_idx + s0), tb = *reinterpret_cast<const uint4 *>(st_idx + s0 + 4);
+        const uint64_t hb = *reinterpret_cast<const uint64_t *>(st_head + s0);
+        t[0] = ta.x, t[1] = ta.y, t[2] = ta.z, t[3] = ta.w, t[4] = tb.x, t[5] = tb.y, t[6] = tb.z, t[7] = tb.w;
+#pragma unroll
+        for (uint32_t q = 0; q < SEG_PER; ++q) hf[q] = ((hb >> (8 * q)) & 1u) != 0;
+    }
+    static_assert(SEG_PER == 8, "");
 #pragma unroll
     for (uint32_t q = 0; q < SEG_PER; ++q) {
-        const uint64_t p = (uint64_t)base + s0 + q;
-        const bool valid = p < n;
-        t[q] = valid ? idx_in[p] : 0u;
-        hf[q] = valid && (p == 0 || head_in[p] != 0);
         if (hf[q]) {
             last = (int)(s0 + q);
             if (first < 0) first = last;
@@ -205,7 +302,11 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
     }
     if (first >= 0) atomicMin(&first_head, (uint32_t)first);
     const int before = block_excl_scan_max(last, red, tid);
+#if SA_EXP & 8
+    tq[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     bool tie = false;
+    uint64_t k0[SEG_PER];
 #pragma unroll
     for (uint32_t q = 0; q < SEG_PER; ++q) {
         const uint32_t slot = s0 + q;
@@ -216,13 +317,18 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
             if (gh[q] < 0) { // the tail of a group that began before the window: keeps its place in front, is not written
                 k = ((uint64_t)slot << 13) | slot;
             } else {
-                const uint64_t r2 = (uint64_t)t[q] + h < n ? rank_old[t[q] + h] : 0u;
+                // (a group owned by the next workgroup stays in slot order: its second ranks are not fetched)
+                const bool mine = (uint32_t)gh[q] < SEG_C;
+                const uint64_t r2 = mine && (uint64_t)t[q] + h < n ? rank_old[t[q] + h] : 0u;
                 k = ((uint64_t)gh[q] << 45) | (r2 << 13) | slot;
-                if (!hf[q] && (uint32_t)gh[q] < SEG_C) tie = true; // a group of more than one entry that this workgroup owns
+                if (!hf[q] && mine) tie = true; // a group of more than one entry that this workgroup owns
             }
         }
-        key[seg_pos(slot)] = k;
+        k0[q] = k;
     }
+    sort8(k0); // (leaves a window without ties as it is: its keys ascend with the slot)
+#pragma unroll
+    for (uint32_t q = 0; q < SEG_PER; ++q) key[seg_pos(s0 + q)] = k0[q];
     if (tie) any_tie = 1; // (every writer writes 1)
     // a group this workgroup owns that runs past the window?
     if (tid == SEG_T - 1) {
@@ -231,7 +337,13 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
     }
     __syncthreads();
 
-    if (any_tie != 0) seg_sort(key, tid);
+#if SA_EXP & 8
+    tq[2] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (any_tie != 0 && !(SA_EXP & 1)) seg_sort(key, tid);
+#if SA_EXP & 8
+    tq[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // slot s now holds the entry that belongs at position base + s.  New heads: the first slot of an old group, or
     // a (group, second rank) that differs from the slot before.
@@ -252,6 +364,9 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
         ngh[q] = nlast;
     }
     const int nbefore = block_excl_scan_max(nlast, red, tid);
+#if SA_EXP & 8
+    tq[4] = __builtin_amdgcn_s_memrealtime();
+#endif
     // the longest new group among those this workgroup owns (measured where the NEXT group, or the end of the text,
     // begins): the host sizes the next round's windows by it
     uint32_t longest = 0;
@@ -273,24 +388,60 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
         if (k != ~0ull && SEG_W - 1 >= F && hd >= 0 && (uint32_t)(k >> 45) < SEG_C) longest = max(longest, SEG_W - (uint32_t)hd);
     }
     if (longest != 0) atomicMax(&max_len, longest);
+    // (every thread has its keys in registers and two barriers behind it: the key array's place is free again and takes
+    // the order and head flags on their way to lane-contiguous stores; the ranks scatter from here)
     uint32_t heads = 0;
+    uint32_t tt[SEG_PER];
+    uint64_t flags8 = 0; // per slot: bit 0 = written by this workgroup, bit 1 = head
 #pragma unroll
     for (uint32_t q = 0; q < SEG_PER; ++q) {
         const uint64_t k = kq[q];
         const uint32_t slot = s0 + q;
-        const uint64_t p = (uint64_t)base + slot;
+        tt[q] = 0;
         if (k == ~0ull || slot < F || (uint32_t)(k >> 45) >= SEG_C) continue; // not this workgroup's to write
         const int g = ngh[q] >= 0 ? ngh[q] : nbefore; // >= F: the entry's own group begins with a head
-        const uint32_t tt = idx_in[base + (uint32_t)(k & 0x1FFFu)]; // (re-read through L2: 32 KiB of LDS less = two workgroups per CU)
-        idx_out[p] = tt;
-        head_out[p] = nh[q] ? 1u : 0u;
-        rank_new[tt] = base + (uint32_t)g + 1u;
+        tt[q] = idx_in[base + (uint32_t)(k & 0x1FFFu)]; // (re-read through L2: 32 KiB of LDS less = two workgroups per CU)
+        rank_new[tt[q]] = base + (uint32_t)g + 1u;
+        flags8 |= (uint64_t)(nh[q] ? 3u : 1u) << (8 * q);
         heads += nh[q] ? 1u : 0u;
     }
+    *reinterpret_cast<uint4 *>(st_idx + s0) = make_uint4(tt[0], tt[1], tt[2], tt[3]);
+    *reinterpret_cast<uint4 *>(st_idx + s0 + 4) = make_uint4(tt[4], tt[5], tt[6], tt[7]);
+    *reinterpret_cast<uint64_t *>(st_head + s0) = flags8;
     if (heads != 0) atomicAdd(&n_heads, heads);
     __syncthreads();
-    if (tid == 0 && n_heads != 0) atomicAdd(&counters[0], n_heads);
-    if (tid == 0 && max_len != 0) atomicMax(&counters[2], max_len);
+#pragma unroll
+    for (uint32_t q = 0; q < SEG_PER; ++q) {
+        const uint32_t slot = q * SEG_T + tid;
+        const uint32_t f = st_head[slot];
+        if ((f & 1u) != 0) {
+            idx_out[base + slot] = st_idx[slot];
+            head_out[base + slot] = f >> 1;
+        }
+    }
+#if SA_EXP & 8
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tq[5] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+        for (int i = 0; i < 5; ++i) atomicAdd(&sa_dbg[i], (unsigned long long)(tq[i + 1] - tq[i]));
+        atomicAdd(&sa_dbg[5], 1ull);
+    }
+#endif
+    if (tid == 0) {
+        if (n_heads != 0) atomicAdd(&counters[0], n_heads);
+        if (max_len != 0) atomicMax(&counters[2], max_len);
+        if (host_out != nullptr) { // the workgroup that finishes last hands the round's counters to the host (pinned memory)
+            // The counters only ever see device-scope atomics, so "mine are performed" is all the ticket needs: a wait
+            // for this wave's memory operations, not a fence (a device-scope fence writes the XCD's L2 back -- with the
+            // round's scattered rank stores in it that made the kernel 45 us longer).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (atomicAdd(&counters[3], 1u) == gridDim.x - 1) {
+                host_out[0] = atomicOr(&counters[0], 0u);
+                host_out[1] = atomicOr(&counters[1], 0u);
+                host_out[2] = atomicOr(&counters[2], 0u);
+            }
+        }
+    }
 }
 
 } // namespace
@@ -350,141 +501,130 @@ int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, 
     int rounds = 0, lds_rounds = 0;
 
     if (ok()) e = hipEventRecord(e0, stream);
-    if (ok()) { // SuffixArrays.cpp:106-113: first two characters
+    if (ok()) { // SuffixArrays.cpp:106-113 and the round k = 4: the first four symbols
         hipLaunchKernelGGL(sa_init_keys, dim3(grid), dim3(block), 0, stream, d_text, n, keys[0], idx[0]);
         e = hipGetLastError();
         size_t ts = tmp_sort;
-        if (ok()) e = rocprim::radix_sort_pairs(tmp, ts, keys[0], keys[1], idx[0], idx[1], (size_t)n, 0, 16, stream);
+        if (ok()) e = rocprim::radix_sort_pairs(tmp, ts, keys[0], keys[1], idx[0], idx[1], (size_t)n, 0, INIT_KEY_BITS, stream);
     }
-    // keys[1] / idx[1] hold the suffixes sorted by their first two characters.  A round (:117 `for (k = 4; k < 2n;
+    // keys[1] / idx[1] hold the suffixes sorted by their first four symbols.  A round (:117 `for (k = 8; k < 2n;
     // k *= 2)`, h = k / 2) = renumber, then order by (rank, rank h further on): in LDS when every group of tied suffixes
     // fits a workgroup's window (sa_segsort_kernel), else through the library sort.
+    const bool debug = getenv("BMX_SA_DEBUG") != nullptr;
     uint32_t groups = 0, longest_group = 0;
+    uint32_t *const gl = counters + 248; // {groups, longest group} of the library path's renumbering
     auto renumber_from_sorted_keys = [&]() { // :119-140 for the library path: head flags, scan, ranks back to text order
-        hipLaunchKernelGGL(sa_head_flags, dim3(grid), dim3(block), 0, stream, keys[1], n, flags);
+        hipLaunchKernelGGL(sa_head_flags, dim3(grid), dim3(block), 0, stream, keys[1], n, flags, gl);
         e = hipGetLastError();
         size_t ts = tmp_scan;
         if (ok()) e = rocprim::inclusive_scan(tmp, ts, flags, scanned, (size_t)n, rocprim::plus<uint32_t>(), stream);
         if (ok()) {
             hipLaunchKernelGGL(sa_scatter_ranks, dim3(grid), dim3(block), 0, stream, idx[1], scanned, n, rank);
+            uint32_t *head_pos = reinterpret_cast<uint32_t *>(keys[0]); // (the sort's input: free now)
+            hipLaunchKernelGGL(sa_group_heads, dim3(grid), dim3(block), 0, stream, flags, scanned, n, head_pos);
+            hipLaunchKernelGGL(sa_group_longest, dim3(grid < 1024 ? grid : 1024), dim3(block), 0, stream, head_pos, scanned, n, gl);
             e = hipGetLastError();
         }
-        uint32_t last = 0;
-        if (ok()) e = hipMemcpyAsync(&last, scanned + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+        uint32_t h2[2] = {0, 0};
+        if (ok()) e = hipMemcpyAsync(h2, gl, sizeof h2, hipMemcpyDeviceToHost, stream);
         if (ok()) e = hipStreamSynchronize(stream);
-        groups = last + 1u;
+        groups = h2[0];
+        longest_group = h2[1];
+        if (debug) fprintf(stderr, "sa: renumbered: groups %u longest %u\n", groups, longest_group);
     };
     uint32_t *idx_cur = idx[1], *idx_alt = idx[0], *flags_cur = flags, *flags_alt = scanned, *rank_cur = rank,
              *rank_alt = reinterpret_cast<uint32_t *>(keys[0]); // (keys[0] is free while the LDS path runs)
+    auto swap_buffers = [&]() {
+        std::swap(idx_cur, idx_alt);
+        std::swap(flags_cur, flags_alt);
+        std::swap(rank_cur, rank_alt);
+    };
+    // entries a workgroup owns per window of SEG_W: all but room for the longest group that can follow them
+    auto owned = [&]() { return std::max(1024u, std::min(SEG_W - 64u, SEG_W - longest_group)); };
     if (ok()) e = hipMemsetAsync(counters, 0, b_cnt, stream);
     if (ok()) renumber_from_sorted_keys();
-    const bool allow_lds = getenv("BMX_SA_NO_LDS") == nullptr;
-    for (uint64_t k = 4; ok() && groups < n && k < 2 * (uint64_t)n; k *= 2) {
+    const bool allow_lds = getenv("BMX_SA_NO_LDS") == nullptr, allow_pipeline = getenv("BMX_SA_NO_PIPELINE") == nullptr;
+    static thread_local uint32_t *hp = nullptr; // pinned: 4 words per round, written by the round's kernel
+    for (uint64_t k = 8; ok() && groups < n && k < 2 * (uint64_t)n; k *= 2) {
         const uint32_t h = (uint32_t)(k / 2);
-        bool done = false;
-        if (allow_lds && rounds < 30 && (longest_group == 0 || longest_group <= SEG_W - 1024)) {
-            uint32_t *cnt = counters + 4 * rounds; // {groups after the round, a group was too long for a window, longest group, -}
-            // entries a workgroup owns per window of SEG_W: all but room for the longest group that can follow them
-            const uint32_t own = longest_group == 0 ? SEG_C0 : std::max(1024u, std::min(SEG_W - 64u, SEG_W - longest_group));
+        const bool fits = allow_lds && rounds < 30 && longest_group <= SEG_W - 1024;
+        if (fits && allow_pipeline && (hp != nullptr || hipHostMalloc(&hp, 64 * 4 * sizeof(uint32_t)) == hipSuccess)) {
+            // From here on every round is an LDS round (groups only split): the rounds are queued back to back and the
+            // host looks at a round's counters -- the kernel's last workgroup puts them into pinned memory -- while the
+            // NEXT round already runs, instead of synchronising the stream after every round.  The round that turns out
+            // to be one too many finds nothing tied and copies its input through.
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            if (hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) e = hipErrorOutOfMemory;
+            int pending = -1; // a round whose counters are on their way
+            auto look = [&](int r) { // wait for round r's counters (the stream is already busy with round r + 1)
+                e = hipEventSynchronize(ev[r & 1]);
+                if (debug) fprintf(stderr, "sa: pipelined round %d: groups %u too_big %u longest %u\n", r, hp[4 * r], hp[4 * r + 1], hp[4 * r + 2]);
+                if (ok() && hp[4 * r + 1] != 0) e = hipErrorAssert; // a group outgrew its window: cannot happen, groups only split
+                if (ok()) {
+                    groups = hp[4 * r];
+                    longest_group = hp[4 * r + 2];
+                }
+            };
+            for (; ok() && groups < n && k < 2 * (uint64_t)n && rounds < 30; k *= 2) {
+                const uint32_t own = owned();
+                const uint32_t nblk = (uint32_t)(((uint64_t)n + own - 1) / own);
+                if (debug) fprintf(stderr, "sa: queue round %d (h %u, own %u, longest known %u)\n", rounds, (uint32_t)(k / 2), own, longest_group);
+                hipLaunchKernelGGL(sa_segsort_kernel, dim3(nblk), dim3(SEG_T), 0, stream, idx_cur, flags_cur, rank_cur, n,
+                                   (uint32_t)(k / 2), own, idx_alt, flags_alt, rank_alt, counters + 4 * rounds, hp + 4 * rounds);
+                e = hipGetLastError();
+                if (ok()) e = hipEventRecord(ev[rounds & 1], stream);
+                swap_buffers();
+                const int mine = rounds;
+                ++rounds;
+                ++lds_rounds;
+                if (pending >= 0 && ok()) {
+                    look(pending);
+                    if (ok() && groups == n) { // the round before this one finished the job: this one was one too many
+                        --rounds;
+                        --lds_rounds;
+                        pending = -1;
+                        break;
+                    }
+                }
+                pending = mine;
+            }
+            if (pending >= 0 && ok()) look(pending);
+            if (ev[0]) (void)hipEventDestroy(ev[0]);
+            if (ev[1]) (void)hipEventDestroy(ev[1]);
+            break;
+        }
+        if (fits) { // one LDS round, the host waits for it (BMX_SA_NO_PIPELINE, or no pinned memory)
+            uint32_t *cnt = counters + 4 * rounds; // {groups after the round, a group was too long for a window, longest group, ticket}
+            const uint32_t own = owned();
             const uint32_t nblk = (uint32_t)(((uint64_t)n + own - 1) / own);
             hipLaunchKernelGGL(sa_segsort_kernel, dim3(nblk), dim3(SEG_T), 0, stream, idx_cur, flags_cur, rank_cur, n, h, own, idx_alt,
-                               flags_alt, rank_alt, cnt);
+                               flags_alt, rank_alt, cnt, (uint32_t *)nullptr);
             e = hipGetLastError();
             uint32_t hc[3] = {0, 0, 0};
             if (ok()) e = hipMemcpyAsync(hc, cnt, sizeof hc, hipMemcpyDeviceToHost, stream);
             if (ok()) e = hipStreamSynchronize(stream);
-            if (getenv("BMX_SA_DEBUG")) {
-                fprintf(stderr, "sa: round %d (h %u, own %u): groups %u too_big %u longest %u\n", rounds, h, own, hc[0], hc[1], hc[2]);
-                if (hc[1] == 0) { // the true longest run of the flags this round wrote
-                    std::vector<uint32_t> f(n);
-                    (void)hipMemcpy(f.data(), flags_alt, (size_t)n * 4, hipMemcpyDeviceToHost);
-                    uint32_t best = 0, best_at = 0, start = 0;
-                    for (uint32_t i = 1; i <= n; ++i)
-                        if (i == n || f[i] != 0) {
-                            if (i - start > best) best = i - start, best_at = start;
-                            start = i;
-                        }
-                    fprintf(stderr, "sa:   true longest %u at position %u (window %u, slot %u; ends at slot %u)\n", best, best_at, best_at / own,
-                            best_at % own, best_at % own + best);
-                }
-            }
-            if (ok() && hc[1] == 0) {
-                std::swap(idx_cur, idx_alt);
-                std::swap(flags_cur, flags_alt);
-                std::swap(rank_cur, rank_alt);
-                groups = hc[0];
-                longest_group = hc[2]; // (groups only split: a bound for every later round)
-                done = true;
-                ++lds_rounds;
-            }
+            if (debug) fprintf(stderr, "sa: round %d (h %u, own %u): groups %u too_big %u longest %u\n", rounds, h, own, hc[0], hc[1], hc[2]);
+            if (ok() && hc[1] != 0) e = hipErrorAssert; // (the longest group is known: cannot happen)
+            swap_buffers();
+            groups = hc[0];
+            longest_group = hc[2]; // (groups only split: a bound for every later round)
+            ++lds_rounds;
+            ++rounds;
+            continue;
         }
         ++rounds;
-        if (done && ok() && getenv("BMX_SA_NO_PIPELINE") == nullptr) {
-            // From here on every round is an LDS round (groups only shrink): the rounds are queued back to back and the
-            // host looks at a round's counters -- copied into pinned memory behind the kernel -- while the NEXT round
-            // already runs, instead of synchronising the stream after every round.  The round that turns out to be one
-            // too many finds nothing tied and copies its input through.
-            static thread_local uint32_t *hp = nullptr; // pinned: 4 words per round
-            if (!hp && hipHostMalloc(&hp, 64 * 4 * sizeof(uint32_t)) != hipSuccess) hp = nullptr;
-            hipEvent_t ev[2] = {nullptr, nullptr};
-            if (hp && hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess) {
-                int pending = -1; // a round whose counters are on their way
-                auto look = [&](int r) { // wait for round r's counters (the stream is already busy with round r + 1)
-                    e = hipEventSynchronize(ev[r & 1]);
-                    if (getenv("BMX_SA_DEBUG")) fprintf(stderr, "sa: pipelined round %d: groups %u too_big %u longest %u\n", r, hp[4 * r], hp[4 * r + 1], hp[4 * r + 2]);
-                    if (ok() && hp[4 * r + 1] != 0) e = hipErrorAssert; // a group outgrew its window: cannot happen, groups only split
-                    if (ok()) {
-                        groups = hp[4 * r];
-                        longest_group = hp[4 * r + 2];
-                    }
-                };
-                for (k *= 2; ok() && groups < n && k < 2 * (uint64_t)n && rounds < 30; k *= 2) {
-                    uint32_t *cnt = counters + 4 * rounds;
-                    const uint32_t own = std::max(1024u, std::min(SEG_W - 64u, SEG_W - longest_group));
-                    const uint32_t nblk = (uint32_t)(((uint64_t)n + own - 1) / own);
-                    if (getenv("BMX_SA_DEBUG")) fprintf(stderr, "sa: queue round %d (h %u, own %u, longest known %u)\n", rounds, (uint32_t)(k / 2), own, longest_group);
-                    hipLaunchKernelGGL(sa_segsort_kernel, dim3(nblk), dim3(SEG_T), 0, stream, idx_cur, flags_cur, rank_cur, n,
-                                       (uint32_t)(k / 2), own, idx_alt, flags_alt, rank_alt, cnt);
-                    e = hipGetLastError();
-                    if (ok()) e = hipMemcpyAsync(hp + 4 * rounds, cnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-                    if (ok()) e = hipEventRecord(ev[rounds & 1], stream);
-                    std::swap(idx_cur, idx_alt);
-                    std::swap(flags_cur, flags_alt);
-                    std::swap(rank_cur, rank_alt);
-                    const int mine = rounds;
-                    ++rounds;
-                    ++lds_rounds;
-                    if (pending >= 0 && ok()) {
-                        look(pending);
-                        if (ok() && groups == n) { // the round before this one finished the job: this one was one too many
-                            --rounds;
-                            --lds_rounds;
-                            pending = -1;
-                            break;
-                        }
-                    }
-                    pending = mine;
-                }
-                if (pending >= 0 && ok()) look(pending);
-            }
-            if (ev[0]) (void)hipEventDestroy(ev[0]);
-            if (ev[1]) (void)hipEventDestroy(ev[1]);
-            if (hp) break; // (without pinned memory: the synchronous loop goes on)
+        if (rank_cur != rank) { // (an LDS round before a library round: cannot happen, groups only split.  Kept correct all the same.)
+            e = hipMemcpyAsync(rank, rank_cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+            if (ok() && idx_cur != idx[1]) e = hipMemcpyAsync(idx[1], idx_cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
         }
-        if (!done && ok()) {
-            if (rank_cur != rank) { // (cannot happen: groups only shrink.  Kept correct all the same.)
-                e = hipMemcpyAsync(rank, rank_cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
-                if (ok() && idx_cur != idx[1]) e = hipMemcpyAsync(idx[1], idx_cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
-            }
-            if (!ok()) break;
-            hipLaunchKernelGGL(sa_build_keys, dim3(grid), dim3(block), 0, stream, rank, n, h, bits, keys[0], idx[0]); // :142-146
-            e = hipGetLastError();
-            size_t ts = tmp_sort;
-            if (ok()) e = rocprim::radix_sort_pairs(tmp, ts, keys[0], keys[1], idx[0], idx[1], (size_t)n, 0, 2 * bits, stream); // :148
-            if (ok()) renumber_from_sorted_keys();
-            idx_cur = idx[1], idx_alt = idx[0], flags_cur = flags, flags_alt = scanned, rank_cur = rank;
-            rank_alt = reinterpret_cast<uint32_t *>(keys[0]);
-        }
+        if (!ok()) break;
+        hipLaunchKernelGGL(sa_build_keys, dim3(grid), dim3(block), 0, stream, rank, n, h, bits, keys[0], idx[0]); // :142-146
+        e = hipGetLastError();
+        size_t ts = tmp_sort;
+        if (ok()) e = rocprim::radix_sort_pairs(tmp, ts, keys[0], keys[1], idx[0], idx[1], (size_t)n, 0, 2 * bits, stream); // :148
+        if (ok()) renumber_from_sorted_keys();
+        idx_cur = idx[1], idx_alt = idx[0], flags_cur = flags, flags_alt = scanned, rank_cur = rank;
+        rank_alt = reinterpret_cast<uint32_t *>(keys[0]);
     }
     if (ok()) {
         hipLaunchKernelGGL(sa_copy_out, dim3(grid), dim3(block), 0, stream, idx_cur, n, d_sa); // :151-153
@@ -492,6 +632,17 @@ int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, 
     }
     if (ok()) e = hipEventRecord(e1, stream);
     if (ok()) e = hipStreamSynchronize(stream);
+#if SA_EXP & 8
+    if (ok()) {
+        unsigned long long d[8] = {0};
+        (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(sa_dbg), sizeof d);
+        const double w = d[5] ? (double)d[5] : 1.0;
+        fprintf(stderr, "sa phases, us per workgroup (%llu workgroups): load+scan %.1f  keys+gather %.1f  sort %.1f  heads+scan %.1f  store %.1f\n", d[5],
+                d[0] / w / 100.0, d[1] / w / 100.0, d[2] / w / 100.0, d[3] / w / 100.0, d[4] / w / 100.0);
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(sa_dbg), z, sizeof z);
+    }
+#endif
     if (ok() && ms_out) (void)hipEventElapsedTime(ms_out, e0, e1);
     if (rounds_out) *rounds_out = rounds | (lds_rounds << 16); // (the shim takes them apart)
 

@@ -138,6 +138,7 @@ struct LdsTables {
     lds_u32 *stage_cnt;   // running count of matches sent to this buffer (never reset: stage_seen is subtracted)
     uint32_t stage_seen;  // its value when this tile's walk began
     lds_u32 *stage_area;  // [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
+    lds_u32 *fill_area;   // fill pass, m = 1..3: 1 KiB per wave (the parking area's place: nothing is parked in that pass)
     uint32_t stage_cap;   // entries per buffer
     uint32_t pat_id;      // which pattern of a multi-pattern pass these tables belong to (else 0): bits 20.. of a parked entry
     lds_u32 *wsum;        // 32 words: per-wave totals of the workgroup scans (count-only mode, fill pass)
@@ -533,67 +534,142 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 // Fill pass for m = 1..3 (dense results are what short patterns produce: one position in four on DNA): the
 // workgroup's waves take consecutive sixteenths of the tile, and INSIDE a wave the lanes interleave by 16-byte
 // chunk -- in round r lane l tests the sixteen window starts of chunk 64 r + l of the wave's piece -- so that
-// position order is (wave, round, lane, byte) and the matches of a round go to consecutive output slots from
-// consecutive lanes: coalesced 8-byte stores.  (A lane that owns a long run of window starts, as in the walkers
-// above, scatters its matches 64 lines wide per instruction.)  The match masks of the counting half stay in
-// registers for the writing half; the scans are DPP.  One barrier inside: every wave of the workgroup is here.
+// position order is (wave, round, lane, byte).  The match masks of the counting half stay in registers for the
+// writing half; the scans are DPP.
+template <uint32_t BLOCK, uint32_t TILE>
+struct ShortTile {
+    static constexpr uint32_t WAVES = BLOCK / 64, PIECE = TILE / WAVES, ROUNDS = (PIECE + 1023) / 1024;
+    static_assert(TILE % (WAVES * 16) == 0, "a wave's piece is a whole number of 16-byte chunks");
+    uint32_t e[ROUNDS]; // per round: one bit per window start of this lane's 16-byte chunk
+    uint32_t first;     // tile-local position of this lane's chunk in round 0
+
+    // the counting half: this lane's matches among the window starts [lo_t, hi_t) of the tile
+    __device__ __forceinline__ uint32_t count(const LdsTables &tb, const uint8_t *T, uint32_t lo_t, uint32_t hi_t, uint32_t wave,
+                                              uint32_t lane)
+    {
+        const uint32_t m = tb.m; // 1..3, wave-uniform
+        const uint32_t p0 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[0]) * 0x01010101u;
+        const uint32_t p1 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 1 ? 1 : 0]) * 0x01010101u;
+        const uint32_t p2 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 2 ? 2 : 0]) * 0x01010101u;
+        // window starts of this wave's piece that are to be reported: [lo_w, hi_w)
+        const uint32_t lo_w = lo_t > wave * PIECE ? lo_t : wave * PIECE;
+        const uint32_t hi_w = hi_t < (wave + 1) * PIECE ? hi_t : (wave + 1) * PIECE;
+        // bit j of the result: a match starts at byte j of the dword `cur` (exact zero-byte test, then the four 0x80
+        // flags gathered into a nibble by one multiplication)
+        auto mask_of = [&](uint32_t cur, uint32_t nxt) -> uint32_t {
+            uint32_t q = eq_bytes(cur, p0);
+            if (m > 1) q &= eq_bytes(__builtin_amdgcn_alignbyte(nxt, cur, 1), p1);
+            if (m > 2) q &= eq_bytes(__builtin_amdgcn_alignbyte(nxt, cur, 2), p2);
+            return (((q >> 7) * 0x00204081u) >> 21) & 0xfu;
+        };
+        first = wave * PIECE + lane * 16;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < ROUNDS; ++r) {
+            const uint32_t d = first + r * 1024; // (chunks past the piece -- the last round of a 4.25 KiB piece -- are masked off)
+            const u32x4 v = *(lds_c128 *)to_lds(T + d);
+            const uint32_t nx = *(lds_c32 *)to_lds(T + d + 16);
+            uint32_t x = mask_of(v.x, v.y) | (mask_of(v.y, v.z) << 4) | (mask_of(v.z, v.w) << 8) | (mask_of(v.w, nx) << 12);
+            if (d < lo_w || d + 16 > hi_w) { // a chunk on the edge of what this wave reports (rare)
+                const uint32_t from = d < lo_w ? (lo_w - d < 16 ? lo_w - d : 16) : 0, to = d + 16 > hi_w ? (hi_w > d ? hi_w - d : 0) : 16;
+                x &= from < to ? (0xffffu << from) & (0xffffu >> (16 - to)) : 0u;
+            }
+            e[r] = x;
+            cnt += (uint32_t)__popc(x);
+        }
+        return cnt;
+    }
+};
+
+// The scan of a short pattern (scan_kernel, WALK 6, with a parking buffer): the same masks, then ONE LDS atomic per
+// wave and tile reserves room for the wave's matches in the workgroup's parking buffer -- every match is counted there,
+// parked or not, as report_hit does it per event -- and the lanes put their tile-local positions behind one another.
+// A wave whose matches no longer fit leaves them out: the tile is dense, the workgroup finds out when it collects
+// the count and the fill pass writes the list.  (Without a fill pass -- experiment builds -- what does not fit goes
+// the direct way, as in report_hit.)  `count_only`: the workgroup has met a dense tile already.
+template <uint32_t BLOCK, uint32_t TILE>
+__device__ __forceinline__ void park_tile_short(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo_t,
+                                                uint32_t hi_t, uint64_t tile_off, uint32_t wave, uint32_t lane, bool count_only)
+{
+    ShortTile<BLOCK, TILE> st;
+    const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane);
+    const uint32_t incl = wave_inclusive_scan(cnt);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) return; // (wave-uniform)
+    const uint32_t addr = (uint32_t)(uintptr_t)tb.stage_cnt;
+    if (count_only) {
+        if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(total) : "memory");
+        return;
+    }
+    uint32_t base = 0;
+    if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(addr), "v"(total) : "memory");
+    base = __builtin_amdgcn_readfirstlane(base) - tb.stage_seen; // matches of this tile counted before this wave's
+    const bool fits = base + total <= tb.stage_cap;
+    if (!fits && a.dense_enabled != 0) return;
+    uint32_t idx = base + (incl - cnt);
+#pragma unroll
+    for (uint32_t r = 0; r < ShortTile<BLOCK, TILE>::ROUNDS; ++r) {
+        uint32_t x = st.e[r];
+        const uint32_t p0 = st.first + r * 1024;
+        while (x != 0) {
+            const uint32_t j = (uint32_t)(__ffs((int)x) - 1);
+            if (fits || idx < tb.stage_cap) {
+                tb.stage[idx] = p0 + j; // (pattern 0: the multi-pattern pass has its own kernel)
+            } else {
+                const uint64_t astart = tile_off + (uint64_t)(p0 + j);
+                emit_hit(a, astart - a.first, astart + a.out_bias, false, 0);
+            }
+            ++idx;
+            x &= x - 1;
+        }
+    }
+}
+
+// The writing half.  A round's matches (up to 1024 of one wave) go to consecutive output slots; a lane holds those
+// of its chunk, so lane l's k-th match belongs (matches of the lanes before) + k slots on: written from there, a
+// store instruction scatters 64 eight-byte pieces over 2 KiB (1 GiB ACGT, m = 1: the pass wrote 2.1 GB at 2.2 TB/s).
+// So the wave first lays the round's chunk-local positions out in slot order in its 1 KiB of LDS (`fill_area`, 2
+// bytes each, 512 at a time) and then stores 64 CONSECUTIVE slots per instruction.  One barrier inside: every wave
+// of the workgroup is here.
 template <uint32_t BLOCK, uint32_t TILE>
 __device__ __forceinline__ void fill_tile_short(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo_t,
                                                 uint32_t hi_t, uint64_t tile_off, uint64_t tile_out, uint32_t wave,
                                                 uint32_t lane)
 {
-    constexpr uint32_t WAVES = BLOCK / 64, PIECE = TILE / WAVES, ROUNDS = (PIECE + 1023) / 1024;
-    static_assert(TILE % (WAVES * 16) == 0, "a wave's piece is a whole number of 16-byte chunks");
-    const uint32_t m = tb.m; // 1..3, wave-uniform
-    const uint32_t p0 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[0]) * 0x01010101u;
-    const uint32_t p1 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 1 ? 1 : 0]) * 0x01010101u;
-    const uint32_t p2 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 2 ? 2 : 0]) * 0x01010101u;
-    // window starts of this wave's piece that are to be reported: [lo_w, hi_w)
-    const uint32_t lo_w = lo_t > wave * PIECE ? lo_t : wave * PIECE;
-    const uint32_t hi_w = hi_t < (wave + 1) * PIECE ? hi_t : (wave + 1) * PIECE;
-    // bit j of the result: a match starts at byte j of the dword `cur` (exact zero-byte test, then the four 0x80 flags
-    // gathered into a nibble by one multiplication)
-    auto mask_of = [&](uint32_t cur, uint32_t nxt) -> uint32_t {
-        uint32_t e = eq_bytes(cur, p0);
-        if (m > 1) e &= eq_bytes(__builtin_amdgcn_alignbyte(nxt, cur, 1), p1);
-        if (m > 2) e &= eq_bytes(__builtin_amdgcn_alignbyte(nxt, cur, 2), p2);
-        return (((e >> 7) * 0x00204081u) >> 21) & 0xfu;
-    };
-    const uint32_t first = wave * PIECE + lane * 16;
-    uint32_t e[ROUNDS]; // per round: one bit per window start of this lane's 16-byte chunk
-    uint32_t cnt = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < ROUNDS; ++r) {
-        const uint32_t d = first + r * 1024; // (chunks past the piece -- the last round of a 4.25 KiB piece -- are masked off)
-        const u32x4 v = *(lds_c128 *)to_lds(T + d);
-        const uint32_t nx = *(lds_c32 *)to_lds(T + d + 16);
-        uint32_t x = mask_of(v.x, v.y) | (mask_of(v.y, v.z) << 4) | (mask_of(v.z, v.w) << 8) | (mask_of(v.w, nx) << 12);
-        if (d < lo_w || d + 16 > hi_w) { // a chunk on the edge of what this wave reports (rare)
-            const uint32_t from = d < lo_w ? (lo_w - d < 16 ? lo_w - d : 16) : 0, to = d + 16 > hi_w ? (hi_w > d ? hi_w - d : 0) : 16;
-            x &= from < to ? (0xffffu << from) & (0xffffu >> (16 - to)) : 0u;
-        }
-        e[r] = x;
-        cnt += (uint32_t)__popc(x);
-    }
+    ShortTile<BLOCK, TILE> st;
+    const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane);
     const uint32_t wave_total = __builtin_amdgcn_readlane(wave_inclusive_scan(cnt), 63);
     if (lane == 0) tb.wsum[wave] = wave_total;
     __syncthreads();
     uint64_t at = tile_out;
     for (uint32_t w = 0; w < wave; ++w) at += tb.wsum[w];
     if (wave_total == 0) return;
+    constexpr uint32_t BATCH = TILE <= 68u * 1024u ? 512u : 128u; // (what fits beside two tiles: bmx_shim.hip sizes the launch by it)
+    static_assert(BLOCK == 1024, "sixteen waves share the area");
+    const uint32_t area = (uint32_t)(uintptr_t)tb.fill_area + wave * (BATCH * 2u); // this wave's two-byte slots (LDS byte address)
 #pragma unroll
-    for (uint32_t r = 0; r < ROUNDS; ++r) {
-        uint32_t x = e[r];
-        const uint32_t c = (uint32_t)__popc(x);
+    for (uint32_t r = 0; r < ShortTile<BLOCK, TILE>::ROUNDS; ++r) {
+        const uint32_t x0 = st.e[r];
+        const uint32_t c = (uint32_t)__popc(x0);
         const uint32_t incl = wave_inclusive_scan(c);
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-        uint64_t slot = at + (incl - c);
-        const uint64_t pos0 = tile_off + (uint64_t)(first + r * 1024) + a.out_bias;
-        while (x != 0) {
-            const uint32_t j = (uint32_t)(__ffs((int)x) - 1);
-            if (slot < a.cap) a.out[slot] = pos0 + j;
-            ++slot;
-            x &= x - 1;
+        const uint64_t pos0 = tile_off + (uint64_t)(wave * ShortTile<BLOCK, TILE>::PIECE + r * 1024) + a.out_bias;
+        for (uint32_t b0 = 0; b0 < total; b0 += BATCH) { // (wave-uniform; one batch unless the round holds more than 512 matches)
+            uint32_t x = x0, idx = incl - c - b0; // slot of this lane's next match inside the batch (wraps below 0: not yet)
+            while (x != 0) {
+                const uint32_t j = (uint32_t)(__ffs((int)x) - 1);
+                if (idx < BATCH) asm volatile("ds_write_b16 %0, %1" ::"v"(area + 2u * idx), "v"(lane * 16u + j) : "memory");
+                ++idx;
+                x &= x - 1;
+            }
+            const uint32_t nb = total - b0 < BATCH ? total - b0 : BATCH;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (uint32_t i = lane; i < nb; i += 64) {
+                uint32_t v;
+                asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(area + 2u * i) : "memory");
+                const uint64_t slot = at + b0 + i;
+                if (slot < a.cap) a.out[slot] = pos0 + v;
+            }
         }
         at += total;
     }
@@ -868,6 +944,7 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
     // parking area for matches: [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
     tb.stage_cap = a.stage_cap;
     tb.stage = tb.stage_cnt = tb.stage_area = nullptr;
+    tb.fill_area = (lds_u32 *)to_lds(end);
     tb.stage_seen = 0;
     if (a.stage_cap != 0) {
         lds_u32 *area = (lds_u32 *)to_lds(end);

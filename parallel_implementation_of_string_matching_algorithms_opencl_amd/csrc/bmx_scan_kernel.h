@@ -211,6 +211,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                 const uint32_t now = __builtin_amdgcn_readfirstlane(parked_now);
                 const uint32_t n_true = now - seen[pp]; // every match of that tile was counted, parked or not
                 seen[pp] = now;
+                if constexpr (WALK == 6 && MODE == 0) // m = 1..3: the fill pass (dense results) starts from these counts
+                    if (a.tile_count != nullptr && tid == 0) a.tile_count[t - gridDim.x - a.tile_begin] = n_true;
                 if (dense_mode && (wg_dense || n_true > tb.stage_cap)) { // (wave-uniform: tb.sink is a per-lane state)
                     // a dense tile: nothing of it is stored -- the fill pass will write the whole list -- and from here
                     // on this workgroup only counts (per lane, one LDS add per wave and tile instead of one per event);
@@ -292,7 +294,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             // half, MODE 9, where every tile's matches go)
             tb.sink = 1;
             tb.lane_cnt = 0;
-            walk_tile();
+            if constexpr (WALK == 6) {
+                ShortTile<BLOCK, TILE> st;
+                const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
+                tb.lane_cnt = st.count(tb, T, lo_t, rem < (uint64_t)TILE ? (uint32_t)rem : TILE, wave, lane);
+            } else {
+                walk_tile();
+            }
             const uint32_t c = wave_sum(tb.lane_cnt);
             if (lane == 0) tb.wsum[wave] = c;
             __syncthreads(); // (the next tile's top barrier separates these reads from the next writes)
@@ -325,7 +333,16 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             if (mine != 0) walk_tile(); // (per lane: a lane without matches has nothing to write)
             }
         } else {
-            walk_tile();
+            if constexpr (WALK == 6 && MODE == 0 && LOADERS == 0 && GRADE == 0) {
+                if (tb.stage_cap != 0) { // m = 1..3: sixteen window starts per 128-bit read, one LDS atomic per wave and tile
+                    const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
+                    park_tile_short<BLOCK, TILE>(a, tb, T, lo_t, rem < (uint64_t)TILE ? (uint32_t)rem : TILE, tile_off, wave, lane, wg_dense);
+                } else {
+                    walk_tile();
+                }
+            } else {
+                walk_tile();
+            }
             if (wg_dense) { // count-only mode (after a dense tile): one LDS add per wave and tile
                 const uint32_t c = wave_sum(tb.lane_cnt);
                 tb.lane_cnt = 0;
@@ -352,6 +369,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         __syncthreads();
         const uint32_t pp = (it & 1u) ^ 1u;
         const uint32_t n_true = __builtin_amdgcn_readfirstlane(*park_cnt(pp)) - seen[pp];
+        if constexpr (WALK == 6 && MODE == 0)
+            if (a.tile_count != nullptr && tid == 0) a.tile_count[t - gridDim.x - a.tile_begin] = n_true;
         if (dense_mode && (wg_dense || n_true > tb.stage_cap)) {
             dense_total += n_true;
             wg_dense = true;

@@ -609,6 +609,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
                 ctx->tile_cap = n_tiles;
             }
             ctx->last_fillable = true;
+            if (m < 4) a.tile_count = ctx->d_tile_count; // the short-pattern scan leaves every tile's count itself
         }
         const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
         if (v.stamps) { // diagnostic build: room for 8 words per wave
@@ -709,11 +710,14 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
         a.tile_base = ctx->d_tile_base;
         a.tile_count = ctx->d_tile_count;
         a.dense_enabled = 0;
-        const uint32_t lds = lds_bytes_with(v, ctx->last_m, 0);
-        HIPCHK(hipFuncSetAttribute((const void *)fill_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // (m = 1..3: 1 KiB per wave in the parking area's place, where the fill pass lays a round's matches out in slot order)
+        const uint32_t lds = lds_bytes_with(v, ctx->last_m, ctx->last_m < 4 ? (v.seg > 68 ? 512u : 2048u) : 0u); // (ShortTile::BATCH x 4)
         HIPCHK(hipFuncSetAttribute((const void *)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(fill_count, dim3(ctx->last_grid), dim3(v.block), lds, stream, a);
-        HIPCHK(hipGetLastError());
+        if (ctx->last_m >= 4) { // (the scan of a short pattern has left the tile counts already)
+            HIPCHK(hipFuncSetAttribute((const void *)fill_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(fill_count, dim3(ctx->last_grid), dim3(v.block), lds, stream, a);
+            HIPCHK(hipGetLastError());
+        }
         hipLaunchKernelGGL(bmx::tile_scan_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, ctx->d_tile_count, n_tiles,
                            ctx->d_tile_base);
         HIPCHK(hipGetLastError());

@@ -75,6 +75,26 @@ def test_gpu_vs_oracle_random(ctx, port):
 
 
 @pytest.mark.gpu
+def test_gpu_first_sort_sees_the_end_of_the_text_as_the_reference_does(ctx, port):
+    """The reference ranks "past the end" as character 96 in its first sort and below everything afterwards
+    (SuffixArrays.cpp:106-111, :142-146), so a suffix sees '`' behind the text if its distance to the end is even.
+    The GPU's first sort takes four symbols at once (the reference's first sort and its round k = 4): texts of both
+    parities, every length up to 40, all byte values (also 96 itself and the negative signed chars) against the oracle."""
+    rng = np.random.default_rng(96)
+    for n in list(range(1, 41)) + [255, 256, 1001, 4096, 4097]:
+        for kind in range(4):
+            if kind == 0:
+                x = rng.integers(1, 256, n).astype(np.uint8)
+            elif kind == 1:
+                x = rng.choice(np.array([95, 96, 97], dtype=np.uint8), n)
+            elif kind == 2:
+                x = rng.choice(np.array([0x80, 0x81, 96], dtype=np.uint8), n)
+            else:
+                x = np.full(n, 96, dtype=np.uint8)
+            assert np.array_equal(ctx.suffix_array(x), port.suffix_array(x)), (n, kind, x[:40].tolist())
+
+
+@pytest.mark.gpu
 def test_gpu_degenerate(ctx):
     assert ctx.suffix_array(b"").size == 0
     assert ctx.suffix_array(b"a").tolist() == [0]
