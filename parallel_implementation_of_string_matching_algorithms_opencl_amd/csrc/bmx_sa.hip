@@ -168,10 +168,17 @@ __device__ __forceinline__ void sort8(uint64_t (&r)[8]) // 19 comparators
 
 // STEPS: the top 1, 2 or 3 of the distances 4, 2, 1 << sh; MIRROR: the first of them is the phase's mirror step
 // (low_mask = 2^p - 1).
+// Slots outside [lo, hi) hold keys that are in place already and below (above) every key inside: a comparator with
+// one of them changes nothing, so a thread none of whose slots lies inside has nothing to do in this round.
 template <int STEPS, bool MIRROR>
-__device__ __forceinline__ void seg_sort_round(uint64_t *key, uint32_t tid, uint32_t sh, uint32_t low_mask)
+__device__ __forceinline__ void seg_sort_round(uint64_t *key, uint32_t tid, uint32_t sh, uint32_t low_mask, uint32_t lo, uint32_t hi)
 {
     const uint32_t base = ((tid >> sh) << (sh + 3)) | (tid & ((1u << sh) - 1u));
+    {
+        const uint32_t top = base | ((MIRROR ? 3u : 7u) << sh); // the thread's lowest slot is `base`, or the mirror image of `top`
+        const uint32_t lowest = MIRROR ? min(base, top ^ low_mask) : base, highest = MIRROR ? max(top, base ^ low_mask) : top;
+        if (highest < lo || lowest >= hi) return;
+    }
     uint32_t pos[8];
     uint64_t r[8];
 #pragma unroll
@@ -182,6 +189,7 @@ __device__ __forceinline__ void seg_sort_round(uint64_t *key, uint32_t tid, uint
     }
 #pragma unroll
     for (int step = 2; step > 2 - STEPS; --step) {
+        if (SA_EXP & 16) break; // (timing: no comparators)
         const uint32_t d = 1u << step;
 #pragma unroll
         for (uint32_t q = 0; q < 8; ++q) {
@@ -195,24 +203,27 @@ __device__ __forceinline__ void seg_sort_round(uint64_t *key, uint32_t tid, uint
 }
 
 // the window holds sorted runs of 8 (sort8); phases 4..13
-__device__ __forceinline__ void seg_sort(uint64_t *key, uint32_t tid)
+__device__ __forceinline__ void seg_sort(uint64_t *key, uint32_t tid, uint32_t lo, uint32_t hi)
 {
+#ifdef SA_WAVE_T
+    tid = (((tid >> 6) & 3u) * 4u + (tid >> 8)) * 64u + (tid & 63u); // wave w takes the slots of wave (w % 4) * 4 + w / 4
+#endif
 #pragma unroll 1
     for (uint32_t p = 4; (1u << p) <= SEG_W; ++p) {
         const uint32_t low_mask = (1u << p) - 1u;
         uint32_t left = p - 3, a = p - 1; // steps at distances 2^a ... 8 go first, `left` of them
         const uint32_t c = (left - 1) % 3 + 1;
-        if (c == 1) seg_sort_round<1, true>(key, tid, a - 2, low_mask);
-        else if (c == 2) seg_sort_round<2, true>(key, tid, a - 2, low_mask);
-        else seg_sort_round<3, true>(key, tid, a - 2, low_mask);
+        if (c == 1) seg_sort_round<1, true>(key, tid, a - 2, low_mask, lo, hi);
+        else if (c == 2) seg_sort_round<2, true>(key, tid, a - 2, low_mask, lo, hi);
+        else seg_sort_round<3, true>(key, tid, a - 2, low_mask, lo, hi);
         __syncthreads();
         a -= c, left -= c;
 #pragma unroll 1
         for (; left != 0; left -= 3, a -= 3) {
-            seg_sort_round<3, false>(key, tid, a - 2, 0);
+            seg_sort_round<3, false>(key, tid, a - 2, 0, lo, hi);
             __syncthreads();
         }
-        seg_sort_round<3, false>(key, tid, 0, 0); // distances 4, 2, 1
+        seg_sort_round<3, false>(key, tid, 0, 0, lo, hi); // distances 4, 2, 1
         __syncthreads();
     }
 }
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
 {
     __shared__ uint64_t key[SEG_W + SEG_W / 8]; // (old group's head slot : 13 | second rank : 32 | slot before the sort : 13), at seg_pos(slot)
     __shared__ int red[SEG_T / 64];
-    __shared__ uint32_t any_tie, first_head, n_heads, max_len;
+    __shared__ uint32_t any_tie, first_head, own_end, n_heads, max_len;
     const uint32_t tid = threadIdx.x;
     const uint32_t base = blockIdx.x * SEG_C;
 #if SA_EXP & 8
@@ -261,6 +272,7 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
     if (tid == 0) {
         any_tie = 0;
         first_head = SEG_W;
+        own_end = SEG_W;
         n_heads = 0;
         max_len = 0;
     }
@@ -301,6 +313,13 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
         gh[q] = last;
     }
     if (first >= 0) atomicMin(&first_head, (uint32_t)first);
+    {   // where the groups this workgroup owns end: the first head at or behind slot SEG_C (or the end of the text)
+        uint32_t e = SEG_W;
+#pragma unroll
+        for (uint32_t q = SEG_PER; q-- > 0;)
+            if (s0 + q >= SEG_C && (hf[q] || (uint64_t)base + s0 + q >= n)) e = s0 + q;
+        if (e != SEG_W) atomicMin(&own_end, e);
+    }
     const int before = block_excl_scan_max(last, red, tid);
 #if SA_EXP & 8
     tq[1] = __builtin_amdgcn_s_memrealtime();
@@ -340,7 +359,7 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
 #if SA_EXP & 8
     tq[2] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (any_tie != 0 && !(SA_EXP & 1)) seg_sort(key, tid);
+    if (any_tie != 0 && !(SA_EXP & 1)) seg_sort(key, tid, first_head, own_end); // (both final: two barriers since their last update)
 #if SA_EXP & 8
     tq[3] = __builtin_amdgcn_s_memrealtime();
 #endif
