@@ -7,19 +7,22 @@
 // `rank_to_suffix` :161-170, a three-stage merge sort :50-149) but renumbers serially on the host
 // every round (:439-453) and copies the suffix structs both ways around it.
 //
-// Here everything stays in HBM, one round is
+// Here everything stays in HBM.  The first sort takes a suffix's first four symbols (the reference's first sort
+// and its round k = 4 in one; sa_init_keys + rocPRIM radix sort).  A doubling round whose groups of tied suffixes
+// fit a workgroup's LDS window is ONE kernel of ours (sa_segsort_kernel: window in, bitonic network on 64-bit
+// keys, new group heads, order / heads / ranks out); the rounds are queued back to back and the host reads a
+// round's counters from pinned memory while the next one runs.  A round with longer groups (small alphabets, the
+// first rounds) goes through the library:
 //     build 64-bit keys (rank[i] << bits | rank[i+h])         sa_build_keys      (ours)
 //     sort (key, index) pairs                                  rocPRIM radix sort (library)
 //     head flags of equal-key runs                             sa_head_flags      (ours)
 //     inclusive scan -> new ranks in sorted order              rocPRIM scan       (library)
-//     scatter ranks back to text order                         sa_scatter_ranks   (ours)
-// and the only thing the host sees per round is one 4-byte "largest rank" (all distinct ->
-// done).  The sort is the hot op of this algorithm and is a plain library sort (keys are
-// already packed so that only 2*ceil(log2(n+1)) bits are sorted); this row is about coverage of
-// the reference's third program, not about a hand-written radix sort.
+//     scatter ranks back to text order, longest group          sa_scatter_ranks, sa_group_heads / _longest (ours)
+// DESIGN.md s7 (f4) has the measurements.
 //
 // Reference quirk kept (see oracle/sa_oracle.c): characters are ranked as SIGNED char - 'a' and
-// "past the end" as -1, i.e. as character 96, in the first round only.
+// "past the end" as -1, i.e. as character 96, in the first sort only (sa_init_keys says what that means for
+// four symbols).
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -145,7 +148,7 @@ __device__ __forceinline__ uint32_t seg_pos(uint32_t s) { return s + (s >> 3); }
 // the 8 keys whose slots differ in bits sh+2..sh and applies up to three consecutive steps (distances 4, 2, 1 << sh)
 // to them in registers.  A round that begins with the mirror step takes, for its upper four registers, the mirror
 // images of the lower four: that set is closed under the following steps too, only its slot order is reversed.
-// 32 rounds = 32 barriers for the 85 steps behind sort8.
+// 32 rounds for the 85 steps behind sort8.
 __device__ __forceinline__ void seg_cx(uint64_t &lo, uint64_t &hi)
 {
     const uint64_t a = lo, b = hi;
@@ -189,7 +192,6 @@ __device__ __forceinline__ void seg_sort_round(uint64_t *key, uint32_t tid, uint
     }
 #pragma unroll
     for (int step = 2; step > 2 - STEPS; --step) {
-        if (SA_EXP & 16) break; // (timing: no comparators)
         const uint32_t d = 1u << step;
 #pragma unroll
         for (uint32_t q = 0; q < 8; ++q) {
@@ -205,27 +207,36 @@ __device__ __forceinline__ void seg_sort_round(uint64_t *key, uint32_t tid, uint
 // the window holds sorted runs of 8 (sort8); phases 4..13
 __device__ __forceinline__ void seg_sort(uint64_t *key, uint32_t tid, uint32_t lo, uint32_t hi)
 {
-#ifdef SA_WAVE_T
-    tid = (((tid >> 6) & 3u) * 4u + (tid >> 8)) * 64u + (tid & 63u); // wave w takes the slots of wave (w % 4) * 4 + w / 4
-#endif
+    // A round with sh <= 6 is WAVE-LOCAL: the 64 threads of wave w take exactly the slots [512 w, 512 w + 512) (and a
+    // mirror step of a phase p <= 9 stays inside them), so between two such rounds no barrier is needed -- a wave's LDS
+    // instructions execute in order -- and the waves drift apart instead of meeting 32 times: 10 barriers are left
+    // (around the rounds with sh = 7 .. 10, and one at the end), and the rounds a wave skips are now time it gives
+    // to the others.
+    bool prev_local = true; // (the keys in LDS were written by the threads that read them first)
+    auto before = [&](uint32_t sh) {
+        const bool local = sh <= 6;
+        if (!(prev_local && local)) __syncthreads(); // (uniform)
+        prev_local = local;
+    };
 #pragma unroll 1
     for (uint32_t p = 4; (1u << p) <= SEG_W; ++p) {
         const uint32_t low_mask = (1u << p) - 1u;
         uint32_t left = p - 3, a = p - 1; // steps at distances 2^a ... 8 go first, `left` of them
         const uint32_t c = (left - 1) % 3 + 1;
+        before(a - 2);
         if (c == 1) seg_sort_round<1, true>(key, tid, a - 2, low_mask, lo, hi);
         else if (c == 2) seg_sort_round<2, true>(key, tid, a - 2, low_mask, lo, hi);
         else seg_sort_round<3, true>(key, tid, a - 2, low_mask, lo, hi);
-        __syncthreads();
         a -= c, left -= c;
 #pragma unroll 1
         for (; left != 0; left -= 3, a -= 3) {
+            before(a - 2);
             seg_sort_round<3, false>(key, tid, a - 2, 0, lo, hi);
-            __syncthreads();
         }
+        before(0);
         seg_sort_round<3, false>(key, tid, 0, 0, lo, hi); // distances 4, 2, 1
-        __syncthreads();
     }
+    __syncthreads();
 }
 
 __device__ __forceinline__ int wave_scan_max(int v) // inclusive prefix maximum over the 64 lanes (DPP; -1 = none)

@@ -54,6 +54,7 @@ struct ScanArgs {
     // every tile's matches in ascending order at tile_base[tile]: no atomics, no sort, whatever the density.
     uint32_t *tile_count;      // fill pass only
     const uint64_t *tile_base; // fill pass only
+    uint32_t *wave_count;      // 1-3-byte patterns: matches per wave piece of every tile (written by the scan, read by the fill pass)
     uint32_t dense_enabled;    // 0: a full parking buffer sends the rest of its tile the direct way (global atomics)
     uint32_t bucket_shift;
     // Several patterns in one pass (bmx_search_device_multi; K == 0: the ordinary search).  `multi` is a blob of
@@ -540,42 +541,53 @@ template <uint32_t BLOCK, uint32_t TILE>
 struct ShortTile {
     static constexpr uint32_t WAVES = BLOCK / 64, PIECE = TILE / WAVES, ROUNDS = (PIECE + 1023) / 1024;
     static_assert(TILE % (WAVES * 16) == 0, "a wave's piece is a whole number of 16-byte chunks");
-    uint32_t e[ROUNDS]; // per round: one bit per window start of this lane's 16-byte chunk
+    uint32_t e[ROUNDS]; // per round: one bit per window start of this lane's 16-byte chunk (count())
     uint32_t first;     // tile-local position of this lane's chunk in round 0
+    uint32_t m, p0, p1, p2, lo_w, hi_w;
 
-    // the counting half: this lane's matches among the window starts [lo_t, hi_t) of the tile
-    __device__ __forceinline__ uint32_t count(const LdsTables &tb, const uint8_t *T, uint32_t lo_t, uint32_t hi_t, uint32_t wave,
-                                              uint32_t lane)
+    __device__ __forceinline__ void setup(const LdsTables &tb, uint32_t lo_t, uint32_t hi_t, uint32_t wave, uint32_t lane)
     {
-        const uint32_t m = tb.m; // 1..3, wave-uniform
-        const uint32_t p0 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[0]) * 0x01010101u;
-        const uint32_t p1 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 1 ? 1 : 0]) * 0x01010101u;
-        const uint32_t p2 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 2 ? 2 : 0]) * 0x01010101u;
+        m = tb.m; // 1..3, wave-uniform
+        p0 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[0]) * 0x01010101u;
+        p1 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 1 ? 1 : 0]) * 0x01010101u;
+        p2 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 2 ? 2 : 0]) * 0x01010101u;
         // window starts of this wave's piece that are to be reported: [lo_w, hi_w)
-        const uint32_t lo_w = lo_t > wave * PIECE ? lo_t : wave * PIECE;
-        const uint32_t hi_w = hi_t < (wave + 1) * PIECE ? hi_t : (wave + 1) * PIECE;
-        // bit j of the result: a match starts at byte j of the dword `cur` (exact zero-byte test, then the four 0x80
-        // flags gathered into a nibble by one multiplication)
+        lo_w = lo_t > wave * PIECE ? lo_t : wave * PIECE;
+        hi_w = hi_t < (wave + 1) * PIECE ? hi_t : (wave + 1) * PIECE;
+        first = wave * PIECE + lane * 16;
+    }
+
+    // round r: bit j = a match starts at byte j of this lane's chunk
+    __device__ __forceinline__ uint32_t mask(const uint8_t *T, uint32_t r) const
+    {
+        // (exact zero-byte test per pattern byte, then the four 0x80 flags of a dword gathered into a nibble by one multiplication)
         auto mask_of = [&](uint32_t cur, uint32_t nxt) -> uint32_t {
             uint32_t q = eq_bytes(cur, p0);
             if (m > 1) q &= eq_bytes(__builtin_amdgcn_alignbyte(nxt, cur, 1), p1);
             if (m > 2) q &= eq_bytes(__builtin_amdgcn_alignbyte(nxt, cur, 2), p2);
             return (((q >> 7) * 0x00204081u) >> 21) & 0xfu;
         };
-        first = wave * PIECE + lane * 16;
+        const uint32_t d = first + r * 1024; // (chunks past the piece -- the last round of a 4.25 KiB piece -- are masked off)
+        const u32x4 v = *(lds_c128 *)to_lds(T + d);
+        const uint32_t nx = *(lds_c32 *)to_lds(T + d + 16);
+        uint32_t x = mask_of(v.x, v.y) | (mask_of(v.y, v.z) << 4) | (mask_of(v.z, v.w) << 8) | (mask_of(v.w, nx) << 12);
+        if (d < lo_w || d + 16 > hi_w) { // a chunk on the edge of what this wave reports (rare)
+            const uint32_t from = d < lo_w ? (lo_w - d < 16 ? lo_w - d : 16) : 0, to = d + 16 > hi_w ? (hi_w > d ? hi_w - d : 0) : 16;
+            x &= from < to ? (0xffffu << from) & (0xffffu >> (16 - to)) : 0u;
+        }
+        return x;
+    }
+
+    // this lane's matches among the window starts [lo_t, hi_t) of the tile; the masks stay in e[]
+    __device__ __forceinline__ uint32_t count(const LdsTables &tb, const uint8_t *T, uint32_t lo_t, uint32_t hi_t, uint32_t wave,
+                                              uint32_t lane)
+    {
+        setup(tb, lo_t, hi_t, wave, lane);
         uint32_t cnt = 0;
 #pragma unroll
         for (uint32_t r = 0; r < ROUNDS; ++r) {
-            const uint32_t d = first + r * 1024; // (chunks past the piece -- the last round of a 4.25 KiB piece -- are masked off)
-            const u32x4 v = *(lds_c128 *)to_lds(T + d);
-            const uint32_t nx = *(lds_c32 *)to_lds(T + d + 16);
-            uint32_t x = mask_of(v.x, v.y) | (mask_of(v.y, v.z) << 4) | (mask_of(v.z, v.w) << 8) | (mask_of(v.w, nx) << 12);
-            if (d < lo_w || d + 16 > hi_w) { // a chunk on the edge of what this wave reports (rare)
-                const uint32_t from = d < lo_w ? (lo_w - d < 16 ? lo_w - d : 16) : 0, to = d + 16 > hi_w ? (hi_w > d ? hi_w - d : 0) : 16;
-                x &= from < to ? (0xffffu << from) & (0xffffu >> (16 - to)) : 0u;
-            }
-            e[r] = x;
-            cnt += (uint32_t)__popc(x);
+            e[r] = mask(T, r);
+            cnt += (uint32_t)__popc(e[r]);
         }
         return cnt;
     }
@@ -589,12 +601,14 @@ struct ShortTile {
 // the direct way, as in report_hit.)  `count_only`: the workgroup has met a dense tile already.
 template <uint32_t BLOCK, uint32_t TILE>
 __device__ __forceinline__ void park_tile_short(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo_t,
-                                                uint32_t hi_t, uint64_t tile_off, uint32_t wave, uint32_t lane, bool count_only)
+                                                uint32_t hi_t, uint64_t tile_off, uint32_t wave, uint32_t lane, bool count_only,
+                                                uint32_t *wave_count /* this tile's BLOCK / 64 words, or null */)
 {
     ShortTile<BLOCK, TILE> st;
     const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane);
     const uint32_t incl = wave_inclusive_scan(cnt);
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    if (wave_count != nullptr && lane == 0) wave_count[wave] = total; // the fill pass starts from these (dense results)
     if (total == 0) return; // (wave-uniform)
     const uint32_t addr = (uint32_t)(uintptr_t)tb.stage_cnt;
     if (count_only) {
@@ -629,46 +643,73 @@ __device__ __forceinline__ void park_tile_short(const ScanArgs &a, const LdsTabl
 // of its chunk, so lane l's k-th match belongs (matches of the lanes before) + k slots on: written from there, a
 // store instruction scatters 64 eight-byte pieces over 2 KiB (1 GiB ACGT, m = 1: the pass wrote 2.1 GB at 2.2 TB/s).
 // So the wave first lays the round's chunk-local positions out in slot order in its 1 KiB of LDS (`fill_area`, 2
-// bytes each, 512 at a time) and then stores 64 CONSECUTIVE slots per instruction.  One barrier inside: every wave
-// of the workgroup is here.
+// bytes each, 512 at a time) and then stores 64 CONSECUTIVE slots per instruction.  No barrier, no counting half: the
+// scan has left the count of every wave piece of every tile (park_tile_short).
 template <uint32_t BLOCK, uint32_t TILE>
 __device__ __forceinline__ void fill_tile_short(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo_t,
-                                                uint32_t hi_t, uint64_t tile_off, uint64_t tile_out, uint32_t wave,
-                                                uint32_t lane)
+                                                uint32_t hi_t, uint64_t tile_off, uint64_t tile_out, const uint32_t *wave_count,
+                                                uint32_t wave, uint32_t lane)
 {
+    // where this wave's matches go: behind those of the tile's earlier waves (the scan left every wave's count)
+    const uint32_t wc = lane < BLOCK / 64 ? wave_count[lane] : 0u;
+    const uint32_t before = __builtin_amdgcn_readlane(wave_inclusive_scan(lane < wave ? wc : 0u), 63);
+    if (__builtin_amdgcn_readlane(wc, wave) == 0) return; // (wave-uniform)
+    uint64_t at = tile_out + before;
     ShortTile<BLOCK, TILE> st;
-    const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane);
-    const uint32_t wave_total = __builtin_amdgcn_readlane(wave_inclusive_scan(cnt), 63);
-    if (lane == 0) tb.wsum[wave] = wave_total;
-    __syncthreads();
-    uint64_t at = tile_out;
-    for (uint32_t w = 0; w < wave; ++w) at += tb.wsum[w];
-    if (wave_total == 0) return;
+    st.setup(tb, lo_t, hi_t, wave, lane);
     constexpr uint32_t BATCH = TILE <= 68u * 1024u ? 512u : 128u; // (what fits beside two tiles: bmx_shim.hip sizes the launch by it)
     static_assert(BLOCK == 1024, "sixteen waves share the area");
     const uint32_t area = (uint32_t)(uintptr_t)tb.fill_area + wave * (BATCH * 2u); // this wave's two-byte slots (LDS byte address)
 #pragma unroll
     for (uint32_t r = 0; r < ShortTile<BLOCK, TILE>::ROUNDS; ++r) {
-        const uint32_t x0 = st.e[r];
+        const uint32_t x0 = st.mask(T, r);
         const uint32_t c = (uint32_t)__popc(x0);
         const uint32_t incl = wave_inclusive_scan(c);
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
         const uint64_t pos0 = tile_off + (uint64_t)(wave * ShortTile<BLOCK, TILE>::PIECE + r * 1024) + a.out_bias;
-        for (uint32_t b0 = 0; b0 < total; b0 += BATCH) { // (wave-uniform; one batch unless the round holds more than 512 matches)
-            uint32_t x = x0, idx = incl - c - b0; // slot of this lane's next match inside the batch (wraps below 0: not yet)
+        if (total <= BATCH) { // (wave-uniform) the usual case: the round's matches fit the wave's area
+            uint32_t x = x0, addr = area + 2u * (incl - c), val = lane * 16u;
             while (x != 0) {
                 const uint32_t j = (uint32_t)(__ffs((int)x) - 1);
-                if (idx < BATCH) asm volatile("ds_write_b16 %0, %1" ::"v"(area + 2u * idx), "v"(lane * 16u + j) : "memory");
-                ++idx;
+                asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(val + j) : "memory");
+                addr += 2;
                 x &= x - 1;
             }
-            const uint32_t nb = total - b0 < BATCH ? total - b0 : BATCH;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            for (uint32_t i = lane; i < nb; i += 64) {
-                uint32_t v;
-                asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(area + 2u * i) : "memory");
-                const uint64_t slot = at + b0 + i;
-                if (slot < a.cap) a.out[slot] = pos0 + v;
+            uint32_t v[BATCH / 64];
+#pragma unroll
+            for (uint32_t i = 0; i < BATCH / 64; ++i) // every slot of the area, all reads in flight together (unconditionally: a
+                                                       // value that is only sometimes the asm's output gets a copy in front of the wait)
+                asm volatile("ds_read_u16 %0, %1" : "=v"(v[i]) : "v"(area + 2u * (i * 64 + lane)) : "memory");
+            // (the reads have landed behind this wait: the values pass THROUGH it, or hipcc schedules their uses in front of it)
+            if constexpr (BATCH / 64 == 8)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1])::"memory");
+            static_assert(BATCH / 64 == 8 || BATCH / 64 == 2, "");
+#pragma unroll
+            for (uint32_t i = 0; i < BATCH / 64; ++i) {
+                if (i * 64 >= total) break; // (wave-uniform)
+                const uint64_t slot = at + i * 64 + lane;
+                if (i * 64 + lane < total && slot < a.cap) a.out[slot] = pos0 + v[i];
+            }
+        } else {
+            for (uint32_t b0 = 0; b0 < total; b0 += BATCH) {
+                uint32_t x = x0, idx = incl - c - b0; // slot of this lane's next match inside the batch (wraps below 0: not yet)
+                while (x != 0) {
+                    const uint32_t j = (uint32_t)(__ffs((int)x) - 1);
+                    if (idx < BATCH) asm volatile("ds_write_b16 %0, %1" ::"v"(area + 2u * idx), "v"(lane * 16u + j) : "memory");
+                    ++idx;
+                    x &= x - 1;
+                }
+                const uint32_t nb = total - b0 < BATCH ? total - b0 : BATCH;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (uint32_t i = lane; i < nb; i += 64) {
+                    uint32_t v;
+                    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(area + 2u * i) : "memory");
+                    const uint64_t slot = at + b0 + i;
+                    if (slot < a.cap) a.out[slot] = pos0 + v;
+                }
             }
         }
         at += total;

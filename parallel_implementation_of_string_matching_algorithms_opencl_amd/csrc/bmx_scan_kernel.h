@@ -317,7 +317,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             if constexpr (WALK == 6) { // m = 1..3: lanes interleaved by dword, coalesced stores
                 const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
                 const uint32_t hi_t = rem < (uint64_t)TILE ? (uint32_t)rem : TILE;
-                fill_tile_short<BLOCK, TILE>(a, tb, T, lo_t, hi_t, tile_off, a.tile_base[t - a.tile_begin], wave, lane);
+                fill_tile_short<BLOCK, TILE>(a, tb, T, lo_t, hi_t, tile_off, a.tile_base[t - a.tile_begin],
+                                             a.wave_count + (t - a.tile_begin) * (uint64_t)NW, wave, lane);
             } else {
             tb.sink = 1;
             tb.lane_cnt = 0;
@@ -336,7 +337,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             if constexpr (WALK == 6 && MODE == 0 && LOADERS == 0 && GRADE == 0) {
                 if (tb.stage_cap != 0) { // m = 1..3: sixteen window starts per 128-bit read, one LDS atomic per wave and tile
                     const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
-                    park_tile_short<BLOCK, TILE>(a, tb, T, lo_t, rem < (uint64_t)TILE ? (uint32_t)rem : TILE, tile_off, wave, lane, wg_dense);
+                    park_tile_short<BLOCK, TILE>(a, tb, T, lo_t, rem < (uint64_t)TILE ? (uint32_t)rem : TILE, tile_off, wave, lane, wg_dense,
+                                                 a.wave_count != nullptr ? a.wave_count + (t - a.tile_begin) * (uint64_t)NW : nullptr);
                 } else {
                     walk_tile();
                 }

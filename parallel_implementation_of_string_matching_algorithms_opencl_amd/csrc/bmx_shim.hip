@@ -228,6 +228,7 @@ struct bmx_ctx {
     unsigned long long *d_count = nullptr; // live match counter; re-armed by order_kernel
     uint32_t *d_tile_count = nullptr;      // matches per tile of the last scan (dense results: input of the fill pass)
     uint64_t *d_tile_base = nullptr;       // their exclusive scan
+    uint32_t *d_wave_count = nullptr;      // 1-3-byte patterns: matches per wave piece of every tile (block / 64 words per tile)
     uint64_t tile_cap = 0;                 // tiles both arrays have room for
     uint8_t *d_multi = nullptr;            // bmx_search_device_multi: the patterns' tables (one blob) and first[]
     uint64_t *d_multi_first = nullptr;
@@ -432,6 +433,7 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (ctx->d_multi_first) (void)hipFree(ctx->d_multi_first);
     if (ctx->d_tile_count) (void)hipFree(ctx->d_tile_count);
     if (ctx->d_tile_base) (void)hipFree(ctx->d_tile_base);
+    if (ctx->d_wave_count) (void)hipFree(ctx->d_wave_count);
     if (ctx->d_bucket_cnt) (void)hipFree(ctx->d_bucket_cnt);
     if (ctx->d_bucket_store) (void)hipFree(ctx->d_bucket_store);
     if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
@@ -563,6 +565,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         a.bucket_store = ctx->d_bucket_store;
         a.bucket_overflow = ctx->d_overflow;
         a.tile_count = nullptr;
+        a.wave_count = nullptr;
         a.dense_enabled = 0;
         a.tile_base = nullptr;
         a.multi = nullptr;
@@ -599,17 +602,17 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         if (fill != nullptr && a.stage_cap != 0 && out != nullptr) {
             const uint64_t n_tiles = a.tile_end - a.tile_begin;
             if (ctx->tile_cap < n_tiles) {
-                if (ctx->d_multi) (void)hipFree(ctx->d_multi);
-    if (ctx->d_multi_first) (void)hipFree(ctx->d_multi_first);
-    if (ctx->d_tile_count) (void)hipFree(ctx->d_tile_count);
+                if (ctx->d_tile_count) (void)hipFree(ctx->d_tile_count);
                 if (ctx->d_tile_base) (void)hipFree(ctx->d_tile_base);
-                ctx->d_tile_count = nullptr, ctx->d_tile_base = nullptr, ctx->tile_cap = 0;
+                if (ctx->d_wave_count) (void)hipFree(ctx->d_wave_count);
+                ctx->d_tile_count = nullptr, ctx->d_tile_base = nullptr, ctx->d_wave_count = nullptr, ctx->tile_cap = 0;
                 HIPCHK(hipMalloc(&ctx->d_tile_count, n_tiles * sizeof(uint32_t)));
                 HIPCHK(hipMalloc(&ctx->d_tile_base, n_tiles * sizeof(uint64_t)));
+                HIPCHK(hipMalloc(&ctx->d_wave_count, n_tiles * 16 * sizeof(uint32_t))); // (1024-thread workgroups)
                 ctx->tile_cap = n_tiles;
             }
             ctx->last_fillable = true;
-            if (m < 4) a.tile_count = ctx->d_tile_count; // the short-pattern scan leaves every tile's count itself
+            if (m < 4) a.tile_count = ctx->d_tile_count, a.wave_count = ctx->d_wave_count; // the short-pattern scan leaves the counts itself
         }
         const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
         if (v.stamps) { // diagnostic build: room for 8 words per wave
@@ -852,6 +855,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     a.bucket_store = ctx->d_bucket_store;
     a.bucket_overflow = ctx->d_overflow;
     a.tile_count = nullptr;
+    a.wave_count = nullptr;
     a.dense_enabled = 0; // dense tiles take the direct path, raise the overflow flag and send the call the exact way
     a.tile_base = nullptr;
     a.stamps = nullptr;

@@ -533,6 +533,32 @@ def test_dense_results_short_patterns(ctx, port):
         ctx.set_variant(0)
 
 
+def test_short_patterns_in_a_shard_view(ctx, port):
+    """Patterns of 1-3 bytes are tested sixteen window starts at a time, a wave piece of the tile per wave
+    (ShortTile): the edges of what a call reports -- the first window start (misaligned pointer), the end of the owned
+    range (n_own, in the middle of a tile, of a wave's piece, of a 16-byte chunk), the last m - 1 bytes -- cut through
+    those pieces.  Sparse, parked and dense results, offsets plus base_offset, against the oracle."""
+    import torch
+
+    rng = np.random.default_rng(1603)
+    n = 1_500_000
+    for alpha in (2, 4, 95):
+        text = (rng.integers(0, alpha, n) + 65).astype(np.uint8)
+        text[700_000:700_300] = 65  # a run: every position matches "A", "AA", "AAA"
+        d_full = torch.from_numpy(text).cuda()
+        out = torch.empty(n + 16, dtype=torch.int64, device="cuda")
+        for m in (1, 2, 3):
+            pat = bytes([65] * m)
+            for off, length, n_own in ((0, n, n), (5, n - 5, 1_000_003), (13, 69632 * 3 + 11, 69632 * 2 + 4351), (1, 69632 + 17, 69632),
+                                       (16, 300_000, 299_998), (7, 100, 50), (3, 5, 5), (0, 4, 2), (9, m, 1)):
+                view = d_full[off:off + length]
+                pos, total = ctx.search_device(view, pat, base_offset=1 << 33, n_own=n_own, out=out)
+                want = port.search(text[off:off + length], pat)
+                want = want[want < n_own] + np.uint64(1 << 33)
+                got = pos.cpu().numpy().astype(np.uint64)
+                assert total == want.size and np.array_equal(got, want), (alpha, m, off, length, n_own, total, want.size)
+
+
 def test_dense_results_take_the_fill_pass(ctx, port):
     """More matches in a tile than its workgroup can park in LDS (one position in four on DNA with a one-byte
     pattern; every position of a...a with 'aa'; SURVEY's hard case): the scan only counts, the fill pass writes

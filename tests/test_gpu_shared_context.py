@@ -54,3 +54,43 @@ def test_suffix_array_edit_distance_search_interleaved_on_one_context(built, por
         assert np.array_equal(c.suffix_array_device(d_text).cpu().numpy(), want_sa)
         check_search(c)
     # the context is destroyed here: each workspace is freed exactly once
+
+
+def test_several_patterns_then_growing_single_searches_on_one_context(built, port):
+    """The multi-pattern pass keeps its table blob and its first[] array in the context; a single search whose text
+    has more tiles than any before re-allocates the per-tile count arrays of the fill pass.  Round 2 had a stray
+    hipFree of the multi-pattern buffers in that re-allocation (freed, not cleared: the next multi-pattern call wrote
+    its tables into freed memory).  Multi -> single (first tile arrays) -> multi -> larger single -> multi, every
+    answer against the oracle, then the context is destroyed (each buffer freed once)."""
+    import torch
+
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import host
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    rng = np.random.default_rng(0xF4EE)
+    small = (rng.integers(0, 4, 400_000) + 65).astype(np.uint8)
+    big = (rng.integers(0, 4, 9_000_000) + 65).astype(np.uint8)
+    pats = [small[100:112].tobytes(), small[5000:5003].tobytes(), small[70_000:70_040].tobytes(), b"A"]
+    d_small, d_big = torch.from_numpy(small).cuda(), torch.from_numpy(big).cuda()
+    out = torch.empty(big.size + 16, dtype=torch.int64, device="cuda")
+    want_multi = [port.search(small, p) for p in pats]
+
+    def check_multi(c):
+        got = c.search_device_multi(d_small, pats, out=out)
+        for k, pos in enumerate(got):
+            assert pos.numel() == want_multi[k].size and np.array_equal(pos.cpu().numpy().astype(np.uint64), want_multi[k]), k
+
+    def check_single(c, d, text, pat):
+        pos, total = c.search_device(d, pat, out=out)
+        want = port.search(text, pat)
+        assert total == want.size and np.array_equal(pos.cpu().numpy().astype(np.uint64), want)
+
+    with host.Context(0) as c:
+        check_multi(c)
+        check_single(c, d_small, small, pats[0])  # the first search with an output list: tile arrays allocated
+        check_multi(c)
+        check_single(c, d_big, big, b"AC")  # more tiles: re-allocated; dense: the fill pass uses them
+        check_multi(c)
+        check_single(c, d_big, big, big[12345:12361].tobytes())
+        check_multi(c)
