@@ -544,6 +544,7 @@ struct ShortTile {
     uint32_t e[ROUNDS]; // per round: one bit per window start of this lane's 16-byte chunk (count())
     uint32_t first;     // tile-local position of this lane's chunk in round 0
     uint32_t m, p0, p1, p2, lo_w, hi_w;
+    uint32_t ref; // the pattern as a little-endian word, 0 in the bytes behind it; 0 if a pattern byte is 0 (see mask())
 
     __device__ __forceinline__ void setup(const LdsTables &tb, uint32_t lo_t, uint32_t hi_t, uint32_t wave, uint32_t lane)
     {
@@ -551,6 +552,8 @@ struct ShortTile {
         p0 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[0]) * 0x01010101u;
         p1 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 1 ? 1 : 0]) * 0x01010101u;
         p2 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 2 ? 2 : 0]) * 0x01010101u;
+        ref = (p0 & 0xffu) | (m > 1 ? p1 & 0xff00u : 0u) | (m > 2 ? p2 & 0xff0000u : 0u);
+        if ((p0 & 0xffu) == 0 || (m > 1 && (p1 & 0xffu) == 0) || (m > 2 && (p2 & 0xffu) == 0)) ref = 0;
         // window starts of this wave's piece that are to be reported: [lo_w, hi_w)
         lo_w = lo_t > wave * PIECE ? lo_t : wave * PIECE;
         hi_w = hi_t < (wave + 1) * PIECE ? hi_t : (wave + 1) * PIECE;
@@ -570,7 +573,32 @@ struct ShortTile {
         const uint32_t d = first + r * 1024; // (chunks past the piece -- the last round of a 4.25 KiB piece -- are masked off)
         const u32x4 v = *(lds_c128 *)to_lds(T + d);
         const uint32_t nx = *(lds_c32 *)to_lds(T + d + 16);
-        uint32_t x = mask_of(v.x, v.y) | (mask_of(v.y, v.z) << 4) | (mask_of(v.z, v.w) << 8) | (mask_of(v.w, nx) << 12);
+        uint32_t x;
+        if (ref != 0) { // (wave-uniform) the usual case
+            // v_mqsad_u32_u8: the sums of absolute differences of the reference word against the four 4-byte windows at
+            // byte offsets 0..3 of a 64-bit operand, reference bytes of 0 left out -- exactly the bytes behind a pattern of
+            // 1-3 bytes; a sum is 0 iff the window begins with the pattern.  One instruction per dword of text instead
+            // of a zero-byte test per pattern byte (105 -> ~45 instructions per round).
+            const u32x4 z = {0, 0, 0, 0};
+            const u32x4 r0 = __builtin_amdgcn_mqsad_u32_u8((uint64_t)v.x | ((uint64_t)v.y << 32), ref, z);
+            const u32x4 r1 = __builtin_amdgcn_mqsad_u32_u8((uint64_t)v.y | ((uint64_t)v.z << 32), ref, z);
+            const u32x4 r2 = __builtin_amdgcn_mqsad_u32_u8((uint64_t)v.z | ((uint64_t)v.w << 32), ref, z);
+            const u32x4 r3 = __builtin_amdgcn_mqsad_u32_u8((uint64_t)v.w | ((uint64_t)nx << 32), ref, z);
+            // sixteen sums -> sixteen bits: x = 2 x + (sum == 0), from the last window start down (a compare into vcc and an
+            // add with carry each; written out, hipcc selects constants with a wait state per compare: 48 slots for 32)
+            x = 0;
+            auto push = [&](uint32_t sum) { asm("v_cmp_eq_u32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : "v"(sum) : "vcc"); };
+#pragma unroll
+            for (int j = 3; j >= 0; --j) push(r3[j]);
+#pragma unroll
+            for (int j = 3; j >= 0; --j) push(r2[j]);
+#pragma unroll
+            for (int j = 3; j >= 0; --j) push(r1[j]);
+#pragma unroll
+            for (int j = 3; j >= 0; --j) push(r0[j]);
+        } else { // a pattern byte of 0 would be left out of the sums: the zero-byte masks
+            x = mask_of(v.x, v.y) | (mask_of(v.y, v.z) << 4) | (mask_of(v.z, v.w) << 8) | (mask_of(v.w, nx) << 12);
+        }
         if (d < lo_w || d + 16 > hi_w) { // a chunk on the edge of what this wave reports (rare)
             const uint32_t from = d < lo_w ? (lo_w - d < 16 ? lo_w - d : 16) : 0, to = d + 16 > hi_w ? (hi_w > d ? hi_w - d : 0) : 16;
             x &= from < to ? (0xffffu << from) & (0xffffu >> (16 - to)) : 0u;

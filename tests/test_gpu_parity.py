@@ -559,6 +559,20 @@ def test_short_patterns_in_a_shard_view(ctx, port):
                 assert total == want.size and np.array_equal(got, want), (alpha, m, off, length, n_own, total, want.size)
 
 
+def test_short_patterns_with_zero_bytes(ctx, port):
+    """v_mqsad_u32_u8 leaves reference bytes of 0 out of its sums, which is how a 1-3-byte pattern is tested against
+    4-byte windows -- and why a pattern that CONTAINS a zero byte takes the zero-byte-mask path instead.  Binary text
+    (bytes 0..2 and 0..255), every pattern of 1-3 bytes over {0, 1, 2} and a few with 0x7f, against the oracle."""
+    rng = np.random.default_rng(7)
+    texts = [rng.integers(0, 3, 200_000).astype(np.uint8), rng.integers(0, 256, 300_000).astype(np.uint8),
+             np.zeros(70_000, dtype=np.uint8)]
+    pats = [bytes(p) for m in (1, 2, 3) for p in np.ndindex(*([3] * m))] + [b"\x7f", b"\x00\x7f", b"\x7f\x00\x01"]  # (pattern bytes are 7-bit: bmx.h)
+    for text in texts:
+        for pat in pats:
+            got = dev_search(ctx, text, pat)
+            assert np.array_equal(got, port.search(text, pat)), (pat, int(text[0]))
+
+
 def test_dense_results_take_the_fill_pass(ctx, port):
     """More matches in a tile than its workgroup can park in LDS (one position in four on DNA with a one-byte
     pattern; every position of a...a with 'aa'; SURVEY's hard case): the scan only counts, the fill pass writes
