@@ -64,6 +64,7 @@ struct ScanArgs {
     // then pattern 1's, ... without knowing about patterns.
     const uint8_t *multi;
     uint32_t multi_bytes, K, bucket_stride;
+    uint32_t multi_qmask; // WALK 21: bit k = pattern k is walked with the 8-gram rule (its 4 KiB shift table is built in LDS)
     uint16_t multi_off[MAX_MULTI], multi_m[MAX_MULTI];
     uint64_t multi_own_end[MAX_MULTI]; // one past the last window start to report, per pattern (aligned coordinates)
     unsigned long long *stamps; // MODE 5 only (diagnostic build): per-wave cycle sums, 8 words per wave

@@ -101,11 +101,39 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     const uint32_t iwave = YOUNG ? wave - (uint32_t)(NW - NL) : wave; // index among the loaders (meaningless otherwise)
     // WALK 20 (several patterns in one pass): their tables, one blob, sit between the tile buffers and the rest
     uint8_t *multi_lds = smem + 2 * buf_bytes;
-    const uint32_t multi_bytes = WALK == 20 ? a.multi_bytes : 0u;
-    if (WALK == 20)
+    constexpr bool MULTI = WALK == 20 || WALK == 21;
+    const uint32_t multi_bytes = MULTI ? a.multi_bytes : 0u;
+    if (MULTI)
         for (uint32_t i = tid * 16; i < multi_bytes; i += BLOCK * 16)
             *reinterpret_cast<uint4 *>(multi_lds + i) = *reinterpret_cast<const uint4 *>(a.multi + i);
-    LdsTables tb = load_tables<WALK == 2, WALK == 3 ? 4 : (WALK == 10 ? 8 : 0)>(a, smem + 2 * buf_bytes + multi_bytes, tid, BLOCK, smem);
+    // WALK 21: behind the blob, one 8-gram shift table (QGRAM_TABLE x u8) per pattern of a.multi_qmask, in pattern order;
+    // built here as load_tables builds the single pattern's (minimum of m - 1 - j per hash through a u32 copy in the
+    // still empty tile area), from the pattern bytes of the blob
+    uint8_t *multi_q = multi_lds + multi_bytes;
+    const uint32_t multi_q_bytes = WALK == 21 ? (uint32_t)__popc(a.multi_qmask) * QGRAM_TABLE : 0u;
+    if constexpr (WALK == 21) {
+        __syncthreads(); // the blob is in LDS
+        uint32_t *s_q = reinterpret_cast<uint32_t *>(smem);
+        uint32_t nq = 0;
+        for (uint32_t k = 0; k < a.K; ++k) {
+            if (((a.multi_qmask >> k) & 1u) == 0) continue; // (uniform)
+            const uint32_t mk = a.multi_m[k];
+            const uint8_t *pk = multi_lds + a.multi_off[k] + 512 + ((2 * mk + 15) & ~15u);
+            for (uint32_t i = tid; i < QGRAM_TABLE; i += BLOCK) s_q[i] = mk - 7;
+            __syncthreads();
+            for (uint32_t j = 7 + tid; j < mk; j += BLOCK) {
+                const uint32_t w0 = (uint32_t)pk[j - 7] | ((uint32_t)pk[j - 6] << 8) | ((uint32_t)pk[j - 5] << 16) | ((uint32_t)pk[j - 4] << 24);
+                const uint32_t w1 = (uint32_t)pk[j - 3] | ((uint32_t)pk[j - 2] << 8) | ((uint32_t)pk[j - 1] << 16) | ((uint32_t)pk[j] << 24);
+                atomicMin(&s_q[qgram8_hash(w0, w1)], mk - 1 - j);
+            }
+            __syncthreads();
+            uint8_t *q8 = multi_q + nq * QGRAM_TABLE;
+            for (uint32_t i = tid; i < QGRAM_TABLE; i += BLOCK) q8[i] = (uint8_t)(s_q[i] < 255u ? s_q[i] : 255u);
+            __syncthreads(); // (the scratch is used again, and it is the first tile's buffer)
+            ++nq;
+        }
+    }
+    LdsTables tb = load_tables<WALK == 2, WALK == 3 ? 4 : (WALK == 10 ? 8 : 0)>(a, smem + 2 * buf_bytes + multi_bytes + multi_q_bytes, tid, BLOCK, smem);
 
     const uint32_t nchunk = buf_bytes >> 4; // 16-B chunks per tile incl. halo
     // PRIO: the waves that are still issuing their share of the DMA outrank the ones that already walk (the
@@ -150,12 +178,17 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     const bool dense_mode = a.dense_enabled != 0 && tb.stage_cap != 0; // lanes may switch to counting (dense tiles)
     bool wg_dense = false; // wave-uniform: this workgroup has met a dense tile and only counts from there on
     unsigned long long dense_total = 0; // ... and what it has counted in such tiles
-    uint64_t t = a.tile_begin + blockIdx.x;
+    // MODE 11 (experiment): every workgroup takes a CONTIGUOUS run of tiles instead of every gridDim.x-th one
+    constexpr bool BLOCKED = MODE == 11;
+    const uint64_t tiles_per_wg = BLOCKED ? (a.tile_end - a.tile_begin + gridDim.x - 1) / gridDim.x : 0;
+    const uint64_t t_step = BLOCKED ? 1 : gridDim.x;
+    const uint64_t t_end = BLOCKED ? (a.tile_begin + (blockIdx.x + 1) * tiles_per_wg < a.tile_end ? a.tile_begin + (blockIdx.x + 1) * tiles_per_wg : a.tile_end) : a.tile_end;
+    uint64_t t = BLOCKED ? a.tile_begin + blockIdx.x * tiles_per_wg : a.tile_begin + blockIdx.x;
     uint32_t it = 0; // tiles walked so far by this workgroup
     uint32_t seen[2] = {0, 0}; // the parking buffers' counts as of their last collection
     auto park_buf = [&](uint32_t p) { return tb.stage_area + p * tb.stage_cap; };
     auto park_cnt = [&](uint32_t p) { return tb.stage_area + 2 * tb.stage_cap + p; };
-    if (t < a.tile_end && issues) issue_tile(t, buf0);
+    if (t < t_end && issues) issue_tile(t, buf0);
     uint32_t cur = 0;
     // MODE 5: where does a tile period go?  s_memtime stamps, summed per wave (the
     // run time of this build means nothing; read the SHARES).
@@ -172,7 +205,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     const unsigned long long st_t0 = MODE == 8 ? __builtin_amdgcn_s_memtime() : st_prev; // MODE 8: the two clock stamps only
     const unsigned long long st_r0 = MODE == 5 || MODE == 8 ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-    for (; t < a.tile_end; t += gridDim.x) {
+    for (; t < t_end; t += t_step) {
         // (A) this tile's DMA has landed for every wave, and every wave has
         //     finished walking the other buffer, which is refilled next.
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
@@ -188,10 +221,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             st_prev = x;
         }
 
-        const uint64_t tn = t + gridDim.x;
+        const uint64_t tn = t + t_step;
         // MODE 6 (staggered issue): the upper half of the waves walks first and issues afterwards
         const bool issue_late = MODE == 6 && wave >= (uint32_t)(BLOCK / 128);
-        const bool issue_now = issues && tn < a.tile_end && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x);
+        const bool issue_now = issues && tn < t_end && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x);
         // (the count of the previous tile's parked matches is requested from LDS before the DMA issue and
         // looked at after it: a read that is waited for on the spot costs every wave ~150 cycles per tile)
         uint32_t parked_now = 0;
@@ -212,7 +245,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                 const uint32_t n_true = now - seen[pp]; // every match of that tile was counted, parked or not
                 seen[pp] = now;
                 if constexpr (WALK == 6 && MODE == 0) // m = 1..3: the fill pass (dense results) starts from these counts
-                    if (a.tile_count != nullptr && tid == 0) a.tile_count[t - gridDim.x - a.tile_begin] = n_true;
+                    if (a.tile_count != nullptr && tid == 0) a.tile_count[t - t_step - a.tile_begin] = n_true;
                 if (dense_mode && (wg_dense || n_true > tb.stage_cap)) { // (wave-uniform: tb.sink is a per-lane state)
                     // a dense tile: nothing of it is stored -- the fill pass will write the whole list -- and from here
                     // on this workgroup only counts (per lane, one LDS add per wave and tile instead of one per event);
@@ -256,7 +289,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                 const uint32_t hi_t = rem < (uint64_t)TILE ? (uint32_t)rem : TILE;
                 if (MODE != 1) walk_lane_sad<WALK == 8>(a, tb, T, tid, lo_t, hi_t, tile_off);
             } else if (MODE != 1 && (!is_loader || SEGI > 0) && (MODE != 3 || wave == 0) && (MODE != 4 || (wave & 3) == 0) && lo < hi) {
-                if constexpr (WALK == 20) { // one walk per pattern over the tile that was fetched once
+                if constexpr (MULTI) { // one walk per pattern over the tile that was fetched once
                     // (Four patterns per lane in ONE loop -- the reads of a round issued together, four independent
                     // chains -- measured slower: 4 GiB, m = 16, K = 4: 2.13 ms against 1.89 ms one after the other.)
                     for (uint32_t k = 0; k < a.K; ++k) {
@@ -270,7 +303,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                         uint32_t hk = seg_lo + seg_len;
                         const uint64_t remk = a.multi_own_end[k] > tile_off ? a.multi_own_end[k] - tile_off : 0;
                         if (remk < (uint64_t)hk) hk = (uint32_t)remk;
-                        if (lo < hk) walk_lane<false>(a, tk, T, lo, hk, tile_off);
+                        if (WALK == 21 && ((a.multi_qmask >> k) & 1u) != 0) { // (uniform) small alphabet, m >= 9: the 8-gram rule
+                            tk.qtab = multi_q + (uint32_t)__popc(a.multi_qmask & ((1u << k) - 1u)) * QGRAM_TABLE;
+                            const uint8_t *pe = tk.pat + mk; // the pattern's last eight bytes as two little-endian words
+                            tk.sad_a = __builtin_amdgcn_readfirstlane((uint32_t)pe[-4] | ((uint32_t)pe[-3] << 8) | ((uint32_t)pe[-2] << 16) | ((uint32_t)pe[-1] << 24));
+                            tk.sad_b = __builtin_amdgcn_readfirstlane((uint32_t)pe[-8] | ((uint32_t)pe[-7] << 8) | ((uint32_t)pe[-6] << 16) | ((uint32_t)pe[-5] << 24));
+                            if (lo < hk) walk_lane_qgram8(a, tk, T, lo, hk, tile_off);
+                        } else if (lo < hk) {
+                            walk_lane<false>(a, tk, T, lo, hk, tile_off);
+                        }
                     }
                 } else if constexpr (WALK == 3)
                     walk_lane_qgram(a, tb, T, lo, hi, tile_off);
@@ -356,7 +397,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         }
         if (issue_now && issue_late) issue_tile(tn, cur ? buf0 : buf1);
         if (prev_n != 0) // the previous tile's matches: reserved before this tile's DMA, stored now
-            finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
+            finish_parked<BLOCK>(a, tb, (t - t_step) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
         ++it;
         if (MODE == 5) {
             const unsigned long long x = stamp();
@@ -372,7 +413,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         const uint32_t pp = (it & 1u) ^ 1u;
         const uint32_t n_true = __builtin_amdgcn_readfirstlane(*park_cnt(pp)) - seen[pp];
         if constexpr (WALK == 6 && MODE == 0)
-            if (a.tile_count != nullptr && tid == 0) a.tile_count[t - gridDim.x - a.tile_begin] = n_true;
+            if (a.tile_count != nullptr && tid == 0) a.tile_count[t - t_step - a.tile_begin] = n_true;
         if (dense_mode && (wg_dense || n_true > tb.stage_cap)) {
             dense_total += n_true;
             wg_dense = true;
@@ -381,7 +422,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             if (prev_n != 0) {
                 unsigned long long reserved = 0;
                 if (tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
-                finish_parked<BLOCK>(a, tb, (t - gridDim.x) * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
+                finish_parked<BLOCK>(a, tb, (t - t_step) * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
             }
         }
     }

@@ -203,6 +203,8 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE(1024, 76, 19, 1, 0)),             // 74
     BMX_EXP(BMX_TILE(1024, 76, 3, 0, 0)),              // 75: variant 29 with sc0 nt
     BMX_EXP(BMX_TILE(1024, 76, 18, 0, 0)),             // 76: variant 29 with sc1 nt
+    BMX_EXP(BMX_TILE(1024, 76, 2, 11, 0)),             // 77: variant 29, every workgroup a contiguous run of tiles
+    BMX_EXP(BMX_TILE(1024, 76, 2, 11, 10)),            // 78: variant 53 (8-gram walker) likewise
 };
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
@@ -569,7 +571,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         a.dense_enabled = 0;
         a.tile_base = nullptr;
         a.multi = nullptr;
-        a.multi_bytes = a.K = a.bucket_stride = 0;
+        a.multi_bytes = a.K = a.bucket_stride = a.multi_qmask = 0;
         a.bucket_shift = 0;
         a.stamps = nullptr;
         a.stage_cap = stage_cap_for(v, m);
@@ -760,6 +762,9 @@ namespace {
 constexpr uint32_t MULTI_BLOB_MAX = bmx::MAX_MULTI * (512 + 2 * ((BMX_MAX_PATTERN + 7) & ~7) + BMX_MAX_PATTERN + 32);
 const auto g_multi_kernel = bmx::scan_kernel<1024, 68, 2, 0, 20>;
 const Variant g_multi_variant = {0, 1024, 68, 2, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+// the same pass with the 8-gram rule for the patterns over small alphabets (one 4 KiB shift table each in LDS: 52 KiB tiles)
+const auto g_multi_kernel_q = bmx::scan_kernel<1024, 52, 2, 0, 21>;
+const Variant g_multi_variant_q = {0, 1024, 52, 2, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 } // namespace
 
 int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own, uint64_t base_offset,
@@ -798,6 +803,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     std::vector<uint8_t> blob;
     bmx::ScanArgs a;
     uint64_t n_starts_max = 0;
+    uint32_t qmask = 0;
     const uintptr_t addr = (uintptr_t)d_text;
     const uint64_t mis = addr & 15u;
     for (int k = 0; k < K; ++k) {
@@ -815,6 +821,13 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
         std::memcpy(blob.data() + off + 512 + (((size_t)2 * m + 15) & ~(size_t)15), pats[k], (size_t)m);
         a.multi_off[k] = (uint16_t)off;
         a.multi_m[k] = (uint16_t)m;
+        {   // the 8-gram rule for this pattern?  As pick_variant decides for a single search: few distinct symbols, m >= 9
+            bool seen[256] = {};
+            int distinct = 0;
+            for (int i = 0; i < m; ++i)
+                if (!seen[(unsigned char)pats[k][i]]) seen[(unsigned char)pats[k][i]] = true, ++distinct;
+            if (m >= 9 && distinct >= 2 && distinct <= 8) qmask |= 1u << k;
+        }
         const uint64_t n_starts = n < (uint64_t)m ? 0 : std::min<uint64_t>(n - (uint64_t)m + 1, n_own);
         a.multi_own_end[k] = mis + n_starts;
         n_starts_max = std::max(n_starts_max, n_starts);
@@ -833,7 +846,17 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
         HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, 4 * sizeof(uint32_t), stream));
     }
     ctx->armed = false;
-    const Variant &v = g_multi_variant;
+    if (getenv("BMX_MULTI_NO_QGRAM")) qmask = 0; // (tools/: A/B runs)
+    const uint32_t q_bytes = (uint32_t)__builtin_popcount(qmask) * bmx::QGRAM_TABLE;
+    {   // (the tables of long patterns can leave no room for the shift tables beside two 52 KiB tiles: byte-wise then)
+        const uint32_t halo = ((uint32_t)(m_max - 1) + 15u) & ~15u;
+        const uint32_t need = 2u * ((uint32_t)unit_bytes(g_multi_variant_q) + halo) + (uint32_t)blob.size() + q_bytes + 512 +
+                              ((((uint32_t)m_max + 7u) & ~7u) * 2) + (((uint32_t)m_max + 15u) & ~15u) + 256 + 128 + 2 * 128 * 4 + 32;
+        if (need > LDS_PER_CU) qmask = 0;
+    }
+    const bool with_q = qmask != 0;
+    const Variant &v = with_q ? g_multi_variant_q : g_multi_variant;
+    const auto kernel = with_q ? g_multi_kernel_q : g_multi_kernel;
     const uint64_t tile = unit_bytes(v);
     bool canonical = true;
     int rc = fill_tables(a.tab, pats[0], ms[0], nullptr, nullptr, &canonical); // (unused by the multi walk; keeps the block defined)
@@ -863,13 +886,14 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     a.halo16 = ((uint32_t)(m_max - 1) + 15u) & ~15u;
     a.multi = ctx->d_multi;
     a.multi_bytes = (uint32_t)blob.size();
+    a.multi_qmask = qmask;
     a.K = (uint32_t)K;
     uint32_t kp2 = 1;
     while ((int)kp2 < K) kp2 <<= 1;
     a.bucket_stride = (uint32_t)bmx::ORDER_BUCKETS / kp2;
     a.bucket_shift = 0;
     while (((n_starts_max - 1) >> a.bucket_shift) >= (uint64_t)a.bucket_stride) ++a.bucket_shift;
-    const uint32_t lds_fixed = 2u * ((uint32_t)tile + a.halo16) + a.multi_bytes + 512 + ((((uint32_t)m_max + 7u) & ~7u) * 2) +
+    const uint32_t lds_fixed = 2u * ((uint32_t)tile + a.halo16) + a.multi_bytes + (with_q ? q_bytes : 0u) + 512 + ((((uint32_t)m_max + 7u) & ~7u) * 2) +
                                (((uint32_t)m_max + 15u) & ~15u) + 256 + 128;
     a.stage_cap = 0;
     for (uint32_t cap = 1024; cap >= 128 && a.stage_cap == 0; cap /= 2)
@@ -879,15 +903,15 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
         ctx->armed = true;
         return one_by_one();
     }
-    static int multi_attr = 0;
-    if (multi_attr < (int)lds) {
-        HIPCHK(hipFuncSetAttribute((const void *)g_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        multi_attr = (int)lds;
+    static int multi_attr[2] = {0, 0};
+    if (multi_attr[with_q] < (int)lds) {
+        HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        multi_attr[with_q] = (int)lds;
     }
     const uint32_t grid = (uint32_t)std::min<uint64_t>(a.tile_end - a.tile_begin, (uint64_t)ctx->num_cu);
     const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
     HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
-    hipLaunchKernelGGL(g_multi_kernel, dim3(grid), dim3(v.block), lds, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(v.block), lds, stream, a);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
     ctx->n_timed++;

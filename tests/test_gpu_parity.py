@@ -667,6 +667,45 @@ def test_several_patterns_in_one_pass(ctx, port):
     assert np.array_equal(dev_search(ctx, text, base[0]), port.search(text, base[0]))
 
 
+def test_several_patterns_over_a_small_alphabet(ctx, port):
+    """The multi-pattern pass walks patterns of nine and more characters over at most eight distinct symbols with the
+    8-gram rule (one 4 KiB shift table per such pattern in LDS, 52 KiB tiles), the others byte-wise, in the same pass:
+    DNA and binary texts, sets that mix both kinds, lengths 9 / 10 / 16 / 64 / 300 next to 3 and 5 and a pattern over
+    20 symbols, shard semantics and a misaligned pointer; every list against the oracle."""
+    import torch
+
+    rng = np.random.default_rng(4242)
+    out = torch.zeros(1 << 20, dtype=torch.int64, device="cuda")
+    for alpha in (4, 2):
+        text = (rng.integers(0, alpha, 6_000_000) + 65).astype(np.uint8)
+        text[3_000_000:3_000_400] = (rng.integers(0, 20, 400) + 70).astype(np.uint8)  # a stretch over more symbols
+        picks = [(1000, 16), (70_000, 64), (123_456, 9), (5, 5), (999, 10), (4_000_000, 300), (3_000_010, 24), (77, 3)]
+        base = [text[a:a + m].tobytes() for a, m in picks]
+        for k, pat in enumerate(base):
+            if len(pat) >= 9:
+                for p in rng.integers(0, text.size - 600, 20 + 5 * k):
+                    text[p:p + len(pat)] = np.frombuffer(pat, dtype=np.uint8)
+        d_all = torch.from_numpy(np.concatenate([np.zeros(3, np.uint8), text])).cuda()
+        wants = None
+        for K in (2, 3, 4, 6, 8):
+            sel = base[:K] if alpha == 4 else [b for b in base[:K] if len(b) >= 9 or K > 4]  # binary text: short patterns are dense
+            if len(sel) < 2:
+                continue
+            for mis in (0, 3):
+                d = d_all[3:] if mis else torch.from_numpy(text).cuda()
+                got = ctx.search_device_multi(d, sel, out=out)
+                for k, pat in enumerate(sel):
+                    want = port.search(text, pat)
+                    assert np.array_equal(got[k].cpu().numpy().astype(np.uint64), want), (alpha, K, mis, k, len(pat))
+        d = torch.from_numpy(text).cuda()
+        sel = [base[0], base[1], base[2], base[4]]
+        got = ctx.search_device_multi(d[500_000:2_500_300], sel, n_own=2_000_000, base_offset=500_000, out=out)
+        for k, pat in enumerate(sel):
+            want = port.search(text[:2_500_300], pat)
+            want = want[(want >= 500_000) & (want < 2_500_000)]
+            assert np.array_equal(got[k].cpu().numpy().astype(np.uint64), want), (alpha, "shard", k)
+
+
 def test_two_searches_in_flight_on_two_streams(port):
     """Two contexts alternate, each on its own stream; a search's scan is released by the end of the
     other context's SCAN kernel (bmx_stream_wait_last_scan), its ordering kernel runs under the next
