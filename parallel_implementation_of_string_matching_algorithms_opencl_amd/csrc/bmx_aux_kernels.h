@@ -42,10 +42,21 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
                                                               const uint64_t *bucket_store,
                                                               uint32_t *bucket_overflow, uint64_t *status,
                                                               uint64_t *host_status, uint64_t seq,
-                                                              uint64_t *multi_first, uint32_t multi_threads_per_pattern)
+                                                              uint64_t *multi_first, uint32_t multi_threads_per_pattern,
+                                                              const uint8_t *text, uint64_t text_n)
 {
     __shared__ uint32_t wave_total[ORDER_THREADS / 64];
+    __shared__ uint32_t seen[8]; // byte values among 4 x 256 bytes of the text just scanned (host_status[6]: see text_sigma, bmx_shim.hip)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 8) seen[tid] = 0;
+    uint32_t sample[4] = {0, 0, 0, 0};
+    const bool sampler = text != nullptr && text_n != 0 && tid < 256; // (four waves: 4 x 256 bytes tell 4 symbols from 60, and
+                                                                      // 4096 LDS atomics on eight words cost this kernel 3 us)
+    if (sampler) {
+        const uint64_t len = text_n < 256 ? text_n : 256;
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) sample[c] = tid < len ? text[(text_n - len) / 3 * c + tid] : text[0];
+    }
     const unsigned long long total = *count;
     const uint32_t scan_err = bucket_overflow[1]; // raised by finish_parked (bmx_scan_common.h): the list is incomplete
     const uint32_t dense = bucket_overflow[2];    // raised by a workgroup that met a dense tile: the list comes from the fill pass
@@ -65,6 +76,10 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
     }
     if (lane == 63) wave_total[wave] = incl;
     __syncthreads(); // also: every thread has read count/overflow before they are reset below
+    if (sampler) {
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) atomicOr(&seen[sample[c] >> 5], 1u << (sample[c] & 31u));
+    }
 
     if (multi_first != nullptr) { // a multi-pattern pass: pattern k's buckets start at thread k * multi_threads_per_pattern
         uint32_t base = incl - mine;
@@ -117,6 +132,9 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
         host_status[0] = total;
         host_status[1] = needs_sort;
         host_status[3] = scan_err;
+        uint32_t sigma = 0; // (0: no sample)
+        for (uint32_t w = 0; w < 8; ++w) sigma += (uint32_t)__popc(seen[w]);
+        host_status[6] = sigma;
         __hip_atomic_store(&host_status[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     cnt4[2 * tid] = make_uint4(0, 0, 0, 0);
@@ -125,6 +143,37 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
 
 // Exclusive scan of the per-tile match counts (dense results): tile_base[t] = matches in tiles before t.  One
 // workgroup; a 4 GiB text has 55 k tiles of 76 KiB = 54 rounds.
+// How many distinct byte values does the text use?  Four 4 KiB samples (start, thirds, end), a 256-bit set in LDS, the
+// count into pinned host memory.  The walker for a pattern depends on the TEXT's alphabet (a nine-letter English word
+// with eight distinct letters looks like a small-alphabet pattern and is not): bmx_shim.hip looks once per text.
+__global__ __launch_bounds__(256) void alphabet_sample_kernel(const uint8_t *text, uint64_t n, uint64_t *host_out, uint64_t seq)
+{
+    __shared__ uint32_t seen[8];
+    if (threadIdx.x < 8) seen[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t len = n < 4096 ? n : 4096;
+    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t c = 0; c < 4; ++c) {
+        const uint64_t at = (n - len) / 3 * c;
+        for (uint64_t i = threadIdx.x; i < len; i += 256) {
+            const uint32_t b = text[at + i];
+#pragma unroll
+            for (uint32_t w = 0; w < 8; ++w) mine[w] |= (b >> 5) == w ? 1u << (b & 31u) : 0u;
+        }
+    }
+#pragma unroll
+    for (uint32_t w = 0; w < 8; ++w)
+        if (mine[w] != 0) atomicOr(&seen[w], mine[w]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sigma = 0;
+        for (uint32_t w = 0; w < 8; ++w) sigma += (uint32_t)__popc(seen[w]);
+        host_out[0] = sigma;
+        __threadfence_system();
+        host_out[1] = seq;
+    }
+}
+
 __global__ __launch_bounds__(ORDER_THREADS) void tile_scan_kernel(const uint32_t *tile_count, uint64_t n_tiles, uint64_t *tile_base)
 {
     __shared__ uint64_t wave_total[ORDER_THREADS / 64];

@@ -54,7 +54,6 @@ struct ScanArgs {
     // every tile's matches in ascending order at tile_base[tile]: no atomics, no sort, whatever the density.
     uint32_t *tile_count;      // fill pass only
     const uint64_t *tile_base; // fill pass only
-    uint32_t *wave_count;      // 1-3-byte patterns: matches per wave piece of every tile (written by the scan, read by the fill pass)
     uint32_t dense_enabled;    // 0: a full parking buffer sends the rest of its tile the direct way (global atomics)
     uint32_t bucket_shift;
     // Several patterns in one pass (bmx_search_device_multi; K == 0: the ordinary search).  `multi` is a blob of
@@ -72,6 +71,9 @@ struct ScanArgs {
     uint32_t halo16;         // (m-1) rounded up to a multiple of 16
     uint32_t stage_cap;      // matches a workgroup can park in LDS per tile before they are appended to HBM (0: none)
     ScanTables tab;
+    // (behind everything else: the offsets of the fields above are what the hot kernel's scalar code was tuned with --
+    // a pointer added in the middle cost config 2's kernel 0.9 %, same instructions, other register assignment)
+    uint32_t *wave_count;      // 1-3-byte patterns: matches per wave piece of every tile (written by the scan, read by the fill pass)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;

@@ -178,12 +178,19 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     const bool dense_mode = a.dense_enabled != 0 && tb.stage_cap != 0; // lanes may switch to counting (dense tiles)
     bool wg_dense = false; // wave-uniform: this workgroup has met a dense tile and only counts from there on
     unsigned long long dense_total = 0; // ... and what it has counted in such tiles
-    // MODE 11 (experiment): every workgroup takes a CONTIGUOUS run of tiles instead of every gridDim.x-th one
+    // MODE 11 (experiment): every workgroup takes a CONTIGUOUS run of tiles instead of every gridDim.x-th one.  (t_step and
+    // t_end are macros, not variables: as variables they made hipcc fetch gridDim.x ahead of the loop and keep it in a
+    // register, and the ordinary kernel -- same instructions otherwise -- lost 0.9 %.)
     constexpr bool BLOCKED = MODE == 11;
-    const uint64_t tiles_per_wg = BLOCKED ? (a.tile_end - a.tile_begin + gridDim.x - 1) / gridDim.x : 0;
-    const uint64_t t_step = BLOCKED ? 1 : gridDim.x;
-    const uint64_t t_end = BLOCKED ? (a.tile_begin + (blockIdx.x + 1) * tiles_per_wg < a.tile_end ? a.tile_begin + (blockIdx.x + 1) * tiles_per_wg : a.tile_end) : a.tile_end;
-    uint64_t t = BLOCKED ? a.tile_begin + blockIdx.x * tiles_per_wg : a.tile_begin + blockIdx.x;
+    uint64_t t_end_blocked = 0;
+    uint64_t t = a.tile_begin + blockIdx.x;
+    if constexpr (BLOCKED) {
+        const uint64_t tiles_per_wg = (a.tile_end - a.tile_begin + gridDim.x - 1) / gridDim.x;
+        t = a.tile_begin + blockIdx.x * tiles_per_wg;
+        t_end_blocked = t + tiles_per_wg < a.tile_end ? t + tiles_per_wg : a.tile_end;
+    }
+#define t_step (BLOCKED ? (uint64_t)1 : (uint64_t)gridDim.x)
+#define t_end (BLOCKED ? t_end_blocked : a.tile_end)
     uint32_t it = 0; // tiles walked so far by this workgroup
     uint32_t seen[2] = {0, 0}; // the parking buffers' counts as of their last collection
     auto park_buf = [&](uint32_t p) { return tb.stage_area + p * tb.stage_cap; };
@@ -430,6 +437,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         a.bucket_overflow[2] = 1u;
         (void)__hip_atomic_fetch_add(a.count, dense_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#undef t_step
+#undef t_end
     if ((MODE == 5 || MODE == 8) && a.stamps != nullptr && lane == 0) {
         unsigned long long *o = a.stamps + ((uint64_t)blockIdx.x * (BLOCK / 64) + wave) * 8;
         o[0] = st_issue;

@@ -215,7 +215,13 @@ struct bmx_ctx {
     int device = 0;
     int num_cu = 256;
     int variant = 0;
-    bool auto_walker = true; // until bmx_set_variant(): variant 0 or 2 by the pattern's alphabet
+    bool auto_walker = true; // until bmx_set_variant(): the walker by the pattern and the text's alphabet (pick_variant)
+    // distinct byte values of the texts seen last (alphabet_sample_kernel), by device pointer and length
+    struct { const void *ptr; uint64_t n; int sigma; } sampled[4] = {};
+    int sampled_next = 0;
+    uint64_t sample_seq = 0;
+    const void *last_text = nullptr; // the text of the search whose status is awaited (its order_kernel samples it again)
+    uint64_t last_text_n = 0;
     int last_variant = 0;    // what the most recent search ran (bmx_scan_geometry reports it)
     int ed_variant = 0;      // edit-distance tile shape (bmx_set_ed_variant)
     float ed_last_ms = -1.0f;
@@ -317,7 +323,16 @@ constexpr int VARIANT_BIG_TILE = 29; // 76 KiB tiles: +2 % on large alphabets, b
 // passes none).  The q-gram walkers skip with a table of their own and only leave a verified window with
 // the caller's shifts, so with tables that shift FURTHER than the canonical ones (unsafe ones: the
 // reference kernel would miss matches) they would not reproduce the reference kernel's list.
-int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical)
+// The walker and geometry for one search.  `sigma` = distinct byte values in samples of the TEXT (0: unknown).
+// Measured, 2 GiB, TB/s (tools/variant_sweep.py):
+//   printable text (sigma 95), byte-wise on 76 KiB tiles / skip loop on 36 KiB tiles with two workgroups per CU /
+//   8-gram: m = 4: 3.6 / 4.4 / -, m = 6: 4.5 / 5.2 / - (4-gram: 3.9), m = 9: 5.4 / 6.0 / 2.6, m = 10: 5.5 / 6.0 / 3.4,
+//   m = 12: 5.8 / 5.9 / 4.6, m = 16: 6.7 / - / 6.4;
+//   ACGT, skip loop / 4-gram / 8-gram: m = 8: 2.1 / 2.3 / 1.6, m = 9: 2.4 / 2.6 / 2.7, m = 10: 2.3 / 3.0 / 3.7, m = 16: 2.3 / 4.1 / 6.4.
+// The q-gram rules pay on small alphabets only, and whether the alphabet is small is a property of the text: the
+// pattern's own distinct symbols (all there was to go by until round 2's second half) say "small" for every short
+// English word -- `Tennessee` ran the 8-gram walker at 2.6 TB/s on English text.
+int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical, int sigma)
 {
     if (!ctx->auto_walker) { // an explicitly chosen variant
         const Variant &v = g_variants[ctx->variant];
@@ -333,18 +348,36 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical)
             ++distinct;
         }
     auto fits = [&](int vi) { return lds_bytes_for(g_variants[vi], m) <= LDS_PER_CU; };
-    if (distinct > 8) // sparse by nature (9^-4 and less): the larger tile
+    const bool large_alphabet = sigma > 0 ? sigma > 8 : distinct > 8;
+    if (large_alphabet) { // sparse by nature (9^-4 and less)
+        if (sigma > 0 && m <= 11 && distinct > 1) return 2; // short patterns: long walks, 32 waves per CU hide them better
         return fits(VARIANT_BIG_TILE) ? VARIANT_BIG_TILE : 0;
+    }
     // sigma^m small = matches every few bytes on a text over the pattern's alphabet (binary, m = 6: one position
     // in 64): what matters then is room to park them, and the default geometry has four times variant 2's
     double expect = 1.0;
     for (int i = 0; i < m && expect < 1e6; ++i) expect *= distinct;
     if (expect < 128.0) return 0;
-    // 2 GiB ACGT: m = 8: 2.1 / 2.3 / 1.6 TB/s (skip loop / 4-gram / 8-gram), m = 9: 2.4 / 2.6 / 2.7, m = 10: 2.3 / 3.0 / 3.7,
-    // m = 16: 2.3 / 4.1 / 6.4
     if (canonical && m >= 9 && fits(VARIANT_QGRAM8)) return VARIANT_QGRAM8;
     if (canonical && m >= 6 && fits(VARIANT_QGRAM4)) return VARIANT_QGRAM4;
     return 2;
+}
+
+// Distinct byte values of the text at d_text (four 4 KiB samples), remembered per (pointer, length): one tiny kernel
+// and one wait of ~20 us when a text is seen for the first time.  0 if it cannot be had.
+int text_sigma(bmx_ctx *ctx, const void *d_text, uint64_t n, hipStream_t stream)
+{
+    if (n == 0 || getenv("BMX_NO_TEXT_SAMPLE")) return 0;
+    for (auto &e : ctx->sampled)
+        if (e.ptr == d_text && e.n == n) return e.sigma;
+    const uint64_t seq = ++ctx->sample_seq;
+    hipLaunchKernelGGL(bmx::alphabet_sample_kernel, dim3(1), dim3(256), 0, stream, (const uint8_t *)d_text, n, ctx->h_status_dev + 4, seq);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return 0;
+    if (__atomic_load_n(&ctx->h_status[5], __ATOMIC_ACQUIRE) != seq) return 0;
+    const int sigma = (int)ctx->h_status[4];
+    auto &slot = ctx->sampled[ctx->sampled_next++ & 3];
+    slot.ptr = d_text, slot.n = n, slot.sigma = sigma;
+    return sigma;
 }
 
 // Convert the caller's int32 tables (or build them) into the kernel-argument layout.
@@ -408,9 +441,9 @@ int bmx_ctx_create(int device, bmx_ctx **out)
         e = hipMalloc(&ctx->d_bucket_store, (size_t)bmx::ORDER_BUCKETS * bmx::ORDER_BUCKET_CAP * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, 4 * sizeof(uint32_t)); // {bucket overflow, scan error, dense, -}
     if (e == hipSuccess) e = hipMalloc(&ctx->d_status, 4 * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 4 * sizeof(uint64_t), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 8 * sizeof(uint64_t), hipHostMallocMapped); // [4], [5]: alphabet sample {sigma, seq}; [6]: order_kernel's sample
     if (e == hipSuccess) {
-        std::memset(ctx->h_status, 0, 4 * sizeof(uint64_t));
+        std::memset(ctx->h_status, 0, 8 * sizeof(uint64_t));
         e = hipHostGetDevicePointer((void **)&ctx->h_status_dev, ctx->h_status, 0);
     }
     for (int i = 0; i < bmx_ctx::EV_RING && e == hipSuccess; ++i) {
@@ -546,7 +579,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
             ctx->armed = true; // nothing was launched
             return rc;
         }
-        const int vi = pick_variant(ctx, pat, m, canonical);
+        const int vi = pick_variant(ctx, pat, m, canonical, ctx->auto_walker && m >= 4 ? text_sigma(ctx, d_text, n, stream) : 0);
         ctx->last_variant = vi;
         const Variant &v = g_variants[vi];
         const uint64_t tile = unit_bytes(v);
@@ -643,7 +676,8 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     // ascending list from the position buckets, {count, needs_sort} for the host, counters re-armed
     hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, out, capacity, ctx->d_count,
                        ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status, ctx->h_status_dev,
-                       ++ctx->seq, (uint64_t *)nullptr, 1u);
+                       ++ctx->seq, (uint64_t *)nullptr, 1u, ctx->auto_walker && !getenv("BMX_NO_TEXT_SAMPLE") ? (const uint8_t *)d_text : nullptr, n);
+    ctx->last_text = d_text, ctx->last_text_n = n;
     HIPCHK(hipGetLastError());
     ctx->armed = true;
     return BMX_OK;
@@ -680,6 +714,9 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
     }
     const uint64_t total = ctx->h_status[0];
     const bool needs_sort = ctx->h_status[1] == 1;
+    if (ctx->h_status[6] != 0) // the text as it is NOW (a caller may put another text at the same address: one search late, not wrong for ever)
+        for (auto &e : ctx->sampled)
+            if (e.ptr == ctx->last_text && e.n == ctx->last_text_n) e.sigma = (int)ctx->h_status[6];
     if (ctx->h_status[3] != 0) { // finish_parked (bmx_scan_common.h): matches were dropped, the list is not the answer
         set_err("scan kernel: a workgroup waited longer than its bound for a slot reservation; result discarded");
         if (n_matches) *n_matches = 0;
@@ -847,6 +884,10 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     }
     ctx->armed = false;
     if (getenv("BMX_MULTI_NO_QGRAM")) qmask = 0; // (tools/: A/B runs)
+    if (qmask != 0) { // ... and only if the TEXT's alphabet is small (pick_variant)
+        const int sigma = text_sigma(ctx, d_text, n, stream);
+        if (sigma > 8) qmask = 0;
+    }
     const uint32_t q_bytes = (uint32_t)__builtin_popcount(qmask) * bmx::QGRAM_TABLE;
     {   // (the tables of long patterns can leave no room for the shift tables beside two 52 KiB tiles: byte-wise then)
         const uint32_t halo = ((uint32_t)(m_max - 1) + 15u) & ~15u;
@@ -919,7 +960,8 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     ctx->last_fillable = false;
     hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, d_match_positions, capacity, ctx->d_count,
                        ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status, ctx->h_status_dev, ++ctx->seq,
-                       ctx->d_multi_first, a.bucket_stride / 8u);
+                       ctx->d_multi_first, a.bucket_stride / 8u, (const uint8_t *)d_text, n);
+    ctx->last_text = d_text, ctx->last_text_n = n;
     HIPCHK(hipGetLastError());
     ctx->armed = true;
     uint64_t total = 0;

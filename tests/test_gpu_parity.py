@@ -533,6 +533,43 @@ def test_dense_results_short_patterns(ctx, port):
         ctx.set_variant(0)
 
 
+def test_walker_follows_the_texts_alphabet(built, port):
+    """Which walker runs is decided by the pattern AND by the alphabet of the text (four 4 KiB samples, looked at once
+    per text): a nine-letter word with few distinct letters is a small-alphabet pattern on DNA (8-gram rule, 76 KiB
+    tiles) and an ordinary word on English-like text (skip loop, 36 KiB tiles, two workgroups per CU -- the 8-gram
+    rule ran there at 2.6 TB/s instead of 6.0).  The lists are the oracle's either way."""
+    import torch
+
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import host
+
+    rng = np.random.default_rng(55)
+    n = 3_000_000
+    english = (rng.integers(0, 60, n) + 60).astype(np.uint8)
+    dna = (rng.integers(0, 4, n) + 65).astype(np.uint8)
+    out = torch.empty(1 << 16, dtype=torch.int64, device="cuda")
+    with host.Context(0) as c:
+        for text, tiles in ((english, {9: 36864, 6: 36864, 16: 77824}), (dna, {9: 77824, 6: 77824, 16: 77824})):
+            pats = {}
+            for m in tiles:
+                pat = text[1000:1000 + m].tobytes()
+                if text is english:  # few distinct letters: "abcabcabc..."
+                    pat = (pat[:3] * 6)[:m]
+                    text[5000 * m:5000 * m + m] = np.frombuffer(pat, dtype=np.uint8)
+                pats[m] = pat
+            # the second text may well get the first one's device address (torch's allocator) and has its length: the first
+            # search on it still goes by what was sampled there before, and puts that right
+            d = None
+            d = torch.from_numpy(text).cuda()
+            pos, total = c.search_device(d, pats[16], out=out)
+            assert np.array_equal(pos.cpu().numpy().astype(np.uint64), port.search(text, pats[16]))
+            for m, tile_bytes in tiles.items():
+                pat = pats[m]
+                pos, total = c.search_device(d, bytes(pat), out=out)
+                want = port.search(text, bytes(pat))
+                assert total == want.size and np.array_equal(pos.cpu().numpy().astype(np.uint64), want), (m, tile_bytes)
+                assert c.geometry(m)["tile_bytes"] == tile_bytes, (m, c.geometry(m))
+
+
 def test_short_patterns_in_a_shard_view(ctx, port):
     """Patterns of 1-3 bytes are tested sixteen window starts at a time, a wave piece of the tile per wave
     (ShortTile): the edges of what a call reports -- the first window start (misaligned pointer), the end of the owned
