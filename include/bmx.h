@@ -127,7 +127,11 @@ int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_o
 /* Same, split in two so a caller can time / overlap / graph-capture the device
  * work: _enqueue launches scan + ordering on `stream` and returns without
  * synchronising; _finish synchronises, reads the count and orders the rare
- * large result (> BMX_SMALL_SORT matches) with a radix sort. */
+ * large result (> BMX_SMALL_SORT matches) with a radix sort.
+ * Which walker runs depends on the alphabet of the TEXT: the first search that sees a (d_text, n) pair counts the
+ * distinct byte values in four 4 KiB samples (one tiny kernel and one wait of ~20 us on `stream`; skipped while the
+ * stream is being captured into a graph, and with BMX_NO_TEXT_SAMPLE=1 in the environment: the pattern's own symbols
+ * decide then); every later search refreshes the count in its ordering kernel.  The match list does not depend on it. */
 int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own,
                               uint64_t base_offset, const char *pat, int32_t m,
                               const int32_t *good, const int32_t *bad,

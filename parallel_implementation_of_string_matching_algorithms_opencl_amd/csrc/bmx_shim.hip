@@ -370,6 +370,8 @@ int text_sigma(bmx_ctx *ctx, const void *d_text, uint64_t n, hipStream_t stream)
     if (n == 0 || getenv("BMX_NO_TEXT_SAMPLE")) return 0;
     for (auto &e : ctx->sampled)
         if (e.ptr == d_text && e.n == n) return e.sigma;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0; // (no wait inside a graph capture)
     const uint64_t seq = ++ctx->sample_seq;
     hipLaunchKernelGGL(bmx::alphabet_sample_kernel, dim3(1), dim3(256), 0, stream, (const uint8_t *)d_text, n, ctx->h_status_dev + 4, seq);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return 0;
