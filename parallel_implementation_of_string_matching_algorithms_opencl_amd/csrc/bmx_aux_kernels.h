@@ -128,6 +128,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
         bucket_overflow[0] = 0;
         bucket_overflow[1] = 0;
         bucket_overflow[2] = 0;
+        bucket_overflow[3] = 0; // (the ticket counter of scan_kernel MODE 12)
         // the host polls host_status[2] (pinned, fine-grained) for this search's sequence number
         host_status[0] = total;
         host_status[1] = needs_sort;

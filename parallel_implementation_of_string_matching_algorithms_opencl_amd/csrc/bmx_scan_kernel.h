@@ -28,6 +28,7 @@
 // caller's alignment.  A chunk is only fetched if it overlaps a valid text byte,
 // hence no read ever touches a 16-B line the caller does not own a byte of.
 #pragma once
+#include <type_traits>
 
 #include "bmx_scan_common.h"
 
@@ -191,6 +192,26 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     }
 #define t_step (BLOCKED ? (uint64_t)1 : (uint64_t)gridDim.x)
 #define t_end (BLOCKED ? t_end_blocked : a.tile_end)
+    // MODE 12: static shares + a stolen tail.  Every launch waits ~3 % for the slowest of its 256 workgroups (§5.3), and
+    // which one that is changes from launch to launch.  A workgroup takes its every-gridDim.x-th tile only up to
+    // steal_begin; the tiles behind (STEAL_RESERVE per workgroup) are handed out by a ticket counter, one per tile period.
+    // The ticket for a tile is requested ONE PERIOD before the tile's DMA is issued -- by thread 0, behind the DMA issue,
+    // so that the loop's own wait for the DMA at the end of the period covers it -- and reaches the others through LDS
+    // at the barrier that every period begins with.  (Tickets for every tile cost 3-10 %, §5.4: the round trip of a
+    // returning atomic is about a tile period under load; here 3-4 % of the tiles pay it.)
+    constexpr bool STEAL = MODE == 12;
+        // (measured, 4 GiB, median of 15 interleaved launches, ms: 8-gram walker on ACGT, m = 64: no pool 0.674, 3 tiles per
+    // workgroup 0.669, 8: 0.657, 16: 0.643, 32: 0.645, 64: 0.677; byte-wise walker on printable text, m = 16: no pool
+    // 0.651, 3: 0.651, 8: 0.648, 16: 0.656)
+    constexpr uint64_t STEAL_RESERVE = WALK == 10 ? 16 : 8, NO_TILE = ~0ull;
+    uint64_t steal_begin = 0, t_prev = NO_TILE, tn_steal = NO_TILE;
+    uint32_t ticket = 0;          // thread 0: the pending request's result
+    bool ticket_pending = false;  // uniform: a request is under way (its result is read at the next loop top)
+    bool pool_dry = false;        // uniform: the counter has run past the pool
+    if constexpr (STEAL) {
+        const uint64_t per_wg = (a.tile_end - a.tile_begin) / gridDim.x;
+        steal_begin = per_wg > 2 * STEAL_RESERVE ? a.tile_begin + (per_wg - STEAL_RESERVE) * gridDim.x : a.tile_end; // (short texts: no pool)
+    }
     uint32_t it = 0; // tiles walked so far by this workgroup
     uint32_t seen[2] = {0, 0}; // the parking buffers' counts as of their last collection
     auto park_buf = [&](uint32_t p) { return tb.stage_area + p * tb.stage_cap; };
@@ -212,10 +233,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     const unsigned long long st_t0 = MODE == 8 ? __builtin_amdgcn_s_memtime() : st_prev; // MODE 8: the two clock stamps only
     const unsigned long long st_r0 = MODE == 5 || MODE == 8 ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-    for (; t < t_end; t += t_step) {
+    // One tile period.  ST: the next tile may come out of the pool (MODE 12's tail); the kernel's ordinary loop and MODE 12's
+    // static phase are the instance without.
+    auto period = [&](auto st_tag) {
+        constexpr bool ST = decltype(st_tag)::value;
         // (A) this tile's DMA has landed for every wave, and every wave has
         //     finished walking the other buffer, which is refilled next.
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
+        if constexpr (ST)
+            if (ticket_pending && tid == 0) tb.wsum[31] = ticket; // (the request of the period before: back by now)
         if (MODE == 5) {
             const unsigned long long x = stamp();
             st_dma += x - st_prev;
@@ -228,15 +254,35 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             st_prev = x;
         }
 
-        const uint64_t tn = t + t_step;
+        uint64_t tn = t + t_step;
+        if constexpr (ST) {
+            if (t + gridDim.x < steal_begin) { // the next tile of the static share
+                tn = t + gridDim.x;
+            } else if (ticket_pending) { // a tile of the pool
+                const uint64_t k = steal_begin + tb.wsum[31];
+                tn = k < a.tile_end ? k : NO_TILE;
+                pool_dry = tn == NO_TILE;
+            } else {
+                tn = NO_TILE;
+            }
+            ticket_pending = false;
+            tn_steal = tn;
+        }
         // MODE 6 (staggered issue): the upper half of the waves walks first and issues afterwards
         const bool issue_late = MODE == 6 && wave >= (uint32_t)(BLOCK / 128);
-        const bool issue_now = issues && tn < t_end && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x);
+        const bool issue_now = issues && (ST ? tn != NO_TILE : tn < t_end) && (MODE != 2 || tn < a.tile_begin + 2ull * gridDim.x);
         // (the count of the previous tile's parked matches is requested from LDS before the DMA issue and
         // looked at after it: a read that is waited for on the spot costs every wave ~150 cycles per tile)
         uint32_t parked_now = 0;
         if (MODE != 1 && tb.stage_cap != 0 && it != 0) parked_now = *park_cnt((it & 1u) ^ 1u);
         if (issue_now && !issue_late) issue_tile(tn, cur ? buf0 : buf1);
+        if constexpr (ST) {
+            // the tile AFTER tn comes out of the pool (tn is the last of the static share, or a pool tile itself): ask now
+            if (tn != NO_TILE && !pool_dry && tn + gridDim.x >= steal_begin) {
+                if (tid == 0) ticket = atomicAdd(a.bucket_overflow + 3, 1u);
+                ticket_pending = true;
+            }
+        }
         // Matches parked while the PREVIOUS tile was walked: reserve their slots now (one global atomic by
         // one thread, not waited for; after the DMA issue, which must not wait for the LDS read here), park
         // this tile's matches in the other buffer meanwhile.
@@ -252,7 +298,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                 const uint32_t n_true = now - seen[pp]; // every match of that tile was counted, parked or not
                 seen[pp] = now;
                 if constexpr (WALK == 6 && MODE == 0) // m = 1..3: the fill pass (dense results) starts from these counts
-                    if (a.tile_count != nullptr && tid == 0) a.tile_count[t - t_step - a.tile_begin] = n_true;
+                    if (a.tile_count != nullptr && tid == 0) a.tile_count[(ST ? t_prev : t - t_step) - a.tile_begin] = n_true;
                 if (dense_mode && (wg_dense || n_true > tb.stage_cap)) { // (wave-uniform: tb.sink is a per-lane state)
                     // a dense tile: nothing of it is stored -- the fill pass will write the whole list -- and from here
                     // on this workgroup only counts (per lane, one LDS add per wave and tile instead of one per event);
@@ -404,7 +450,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         }
         if (issue_now && issue_late) issue_tile(tn, cur ? buf0 : buf1);
         if (prev_n != 0) // the previous tile's matches: reserved before this tile's DMA, stored now
-            finish_parked<BLOCK>(a, tb, (t - t_step) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
+            finish_parked<BLOCK>(a, tb, (ST ? t_prev : t - t_step) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
         ++it;
         if (MODE == 5) {
             const unsigned long long x = stamp();
@@ -413,6 +459,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             ++st_n;
         }
         cur ^= 1;
+        if constexpr (ST) t_prev = t;
+    };
+    if constexpr (STEAL) {
+        // static phase: the next tile is the share's next tile and no ticket is needed yet -- the loop of the ordinary kernel
+        for (; t + 2 * (uint64_t)gridDim.x < steal_begin; t += gridDim.x) period(std::false_type{});
+        if (it != 0) t_prev = t - gridDim.x;
+        for (; t != NO_TILE; t = tn_steal) period(std::true_type{});
+    } else {
+        for (; t < t_end; t += t_step) period(std::false_type{});
     }
     if (MODE != 1 && tb.stage_cap != 0 && it != 0) { // what the last tile left parked
         __builtin_amdgcn_s_waitcnt(0);
@@ -420,7 +475,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         const uint32_t pp = (it & 1u) ^ 1u;
         const uint32_t n_true = __builtin_amdgcn_readfirstlane(*park_cnt(pp)) - seen[pp];
         if constexpr (WALK == 6 && MODE == 0)
-            if (a.tile_count != nullptr && tid == 0) a.tile_count[t - t_step - a.tile_begin] = n_true;
+            if (a.tile_count != nullptr && tid == 0) a.tile_count[(STEAL ? t_prev : t - t_step) - a.tile_begin] = n_true;
         if (dense_mode && (wg_dense || n_true > tb.stage_cap)) {
             dense_total += n_true;
             wg_dense = true;
@@ -429,7 +484,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             if (prev_n != 0) {
                 unsigned long long reserved = 0;
                 if (tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
-                finish_parked<BLOCK>(a, tb, (t - t_step) * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
+                finish_parked<BLOCK>(a, tb, (STEAL ? t_prev : t - t_step) * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
             }
         }
     }

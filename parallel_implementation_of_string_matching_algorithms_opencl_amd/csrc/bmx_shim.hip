@@ -108,6 +108,11 @@ struct Variant {
     {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 3 ? 4 : ((W) == 10 ? 8 : 0), bmx::scan_kernel<B, S, AUX, 0, W>, \
      bmx::scan_kernel<B, S, AUX, 0, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>, \
      bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>}
+// ... and with static shares + a stolen tail (scan_kernel MODE 12); short patterns and the fill pass as in BMX_TILE_F
+#define BMX_TILE_S(B, S, AUX, W) \
+    {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 3 ? 4 : ((W) == 10 ? 8 : 0), bmx::scan_kernel<B, S, AUX, 12, W>, \
+     bmx::scan_kernel<B, S, AUX, 0, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>, \
+     bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>}
 #define BMX_TILE_W32(B, S, AUX, MODE, W) /* 32 waves per CU: the 80-SGPR build */ \
     {0, B, S, 2, 0, 0, (MODE) == 5, (W) == 3, (W) == 3 ? 4 : 0, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, MODE, 6, 0>, \
      (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 0> : nullptr, (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 6> : nullptr, \
@@ -178,7 +183,7 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE(1024, 68, 2, 5, 3)),              // 50: stamps of 24 (4-gram walker)
     BMX_EXP(BMX_TILE(1024, 68, 2, 8, 3)),              // 51: clock stamps of 24
     BMX_EXP(BMX_TILE(1024, 76, 2, 0, 9)),              // 52: 76 KiB tiles, byte-wise walker behind the register bitmap (valid lists; slower)
-    BMX_TILE_F(1024, 76, 2, 10),                       // 53: PRODUCT -- 76 KiB tiles, 8-gram walker (m >= 8)
+    BMX_TILE_S(1024, 76, 2, 10),                       // 53: PRODUCT -- 76 KiB tiles, 8-gram walker (m >= 8), static shares + a stolen tail
     BMX_TILE_F(1024, 76, 2, 3),                        // 54: PRODUCT -- 76 KiB tiles, 4-gram walker
     BMX_EXP(BMX_TILE(1024, 76, 2, 5, 9)),              // 55: stamps of 52
     BMX_EXP(BMX_TILE(1024, 76, 2, 5, 10)),             // 56: stamps of 53
@@ -205,6 +210,8 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE(1024, 76, 18, 0, 0)),             // 76: variant 29 with sc1 nt
     BMX_EXP(BMX_TILE(1024, 76, 2, 11, 0)),             // 77: variant 29, every workgroup a contiguous run of tiles
     BMX_EXP(BMX_TILE(1024, 76, 2, 11, 10)),            // 78: variant 53 (8-gram walker) likewise
+    BMX_EXP(BMX_TILE_S(1024, 76, 2, 0)),               // 79: variant 29 with a stolen tail (MODE 12)
+    BMX_EXP(BMX_TILE_F(1024, 76, 2, 10)),              // 80: variant 53 without its stolen tail (static shares only)
 };
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
