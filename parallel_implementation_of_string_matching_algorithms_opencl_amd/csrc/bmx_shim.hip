@@ -210,7 +210,7 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE(1024, 76, 18, 0, 0)),             // 76: variant 29 with sc1 nt
     BMX_EXP(BMX_TILE(1024, 76, 2, 11, 0)),             // 77: variant 29, every workgroup a contiguous run of tiles
     BMX_EXP(BMX_TILE(1024, 76, 2, 11, 10)),            // 78: variant 53 (8-gram walker) likewise
-    BMX_EXP(BMX_TILE_S(1024, 76, 2, 0)),               // 79: variant 29 with a stolen tail (MODE 12)
+    BMX_TILE_S(1024, 76, 2, 0),                        // 79: PRODUCT -- variant 29 with a stolen tail (scan_kernel MODE 12): long patterns on large alphabets
     BMX_EXP(BMX_TILE_F(1024, 76, 2, 10)),              // 80: variant 53 without its stolen tail (static shares only)
 };
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
@@ -324,6 +324,7 @@ uint32_t lds_bytes_for(const Variant &v, int32_t m);
 
 constexpr int VARIANT_QGRAM4 = 54;   // 4-gram walker, 76 KiB tiles
 constexpr int VARIANT_QGRAM8 = 53;   // 8-gram walker, 76 KiB tiles
+constexpr int VARIANT_BIG_TILE_STEAL = 79; // ... with a stolen tail: the shorter the walk, the more a launch waits for its slowest workgroup
 constexpr int VARIANT_BIG_TILE = 29; // 76 KiB tiles: +2 % on large alphabets, but room for 512 parked matches per tile only
 
 // `canonical`: the shift tables in use are the ones bmx_build_tables makes (always so when the caller
@@ -358,6 +359,9 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
     const bool large_alphabet = sigma > 0 ? sigma > 8 : distinct > 8;
     if (large_alphabet) { // sparse by nature (9^-4 and less)
         if (sigma > 0 && m <= 11 && distinct > 1) return 2; // short patterns: long walks, 32 waves per CU hide them better
+        // (4 GiB printable text, byte-wise walker, ms without / with the stolen tail: m = 16: 0.651 / 0.653, m = 24: 0.643 / 0.640,
+        // m = 32: 0.672 / 0.649, m = 48: 0.693 / 0.675, m = 64: 0.680 / 0.655)
+        if (m >= 28 && fits(VARIANT_BIG_TILE_STEAL)) return VARIANT_BIG_TILE_STEAL;
         return fits(VARIANT_BIG_TILE) ? VARIANT_BIG_TILE : 0;
     }
     // sigma^m small = matches every few bytes on a text over the pattern's alphabet (binary, m = 6: one position
