@@ -184,7 +184,7 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE(1024, 68, 2, 8, 3)),              // 51: clock stamps of 24
     BMX_EXP(BMX_TILE(1024, 76, 2, 0, 9)),              // 52: 76 KiB tiles, byte-wise walker behind the register bitmap (valid lists; slower)
     BMX_TILE_S(1024, 76, 2, 10),                       // 53: PRODUCT -- 76 KiB tiles, 8-gram walker (m >= 8), static shares + a stolen tail
-    BMX_TILE_F(1024, 76, 2, 3),                        // 54: PRODUCT -- 76 KiB tiles, 4-gram walker
+    BMX_TILE_S(1024, 76, 2, 3),                        // 54: PRODUCT -- 76 KiB tiles, 4-gram walker, static shares + a stolen tail (ACGT, m = 8: +2 %)
     BMX_EXP(BMX_TILE(1024, 76, 2, 5, 9)),              // 55: stamps of 52
     BMX_EXP(BMX_TILE(1024, 76, 2, 5, 10)),             // 56: stamps of 53
     BMX_EXP(BMX_RING_P(1024, 52, 2, 0, 1, 0)),         // 57: ring, DMA only, 3 x 52 KiB
@@ -212,6 +212,8 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE(1024, 76, 2, 11, 10)),            // 78: variant 53 (8-gram walker) likewise
     BMX_TILE_S(1024, 76, 2, 0),                        // 79: PRODUCT -- variant 29 with a stolen tail (scan_kernel MODE 12): long patterns on large alphabets
     BMX_EXP(BMX_TILE_F(1024, 76, 2, 10)),              // 80: variant 53 without its stolen tail (static shares only)
+    BMX_EXP(BMX_TILE_F(1024, 76, 2, 3)),               // 81: variant 54 (4-gram walker) without its stolen tail
+    BMX_EXP(BMX_TILE_W32(1024, 36, 2, 12, 2)),         // 82: variant 2 (skip loop, two workgroups per CU) with a stolen tail: nothing gained (printable m = 8: 0.750 vs 0.742 ms)
 };
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
