@@ -33,7 +33,7 @@ is present, else the C restatement -- timed on this host over the same text,
 which doubles as the full-size bit-exactness check of the GPU match list).
 The timed region keeps the scan kernels of consecutive searches apart, so that a
 launch's duration is the kernel's; what the same stream of searches reaches when
-they may share the GPU is measured behind it and reported as
+they may share the GPU is measured behind it with --measure-overlap and reported as
 config.whole_job_GBps_if_scans_may_overlap (never `value`; --overlap-scans times
 the whole region that way).
 """
@@ -63,6 +63,9 @@ def parse_args(argv=None):
                     help="let the scan kernels of consecutive searches share the GPU (a CU holds one workgroup, so search "
                          "k+1's workgroups start wherever search k's are done): higher whole-job throughput; a launch's own "
                          "duration then says nothing, so the roofline object is not comparable -- not the default")
+    ap.add_argument("--measure-overlap", action="store_true",
+                    help="behind the timed region, time the same searches once more with overlapping scans and report it as "
+                         "config.whole_job_GBps_if_scans_may_overlap (off by default: its launches would be in every profile of this command)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="searches in flight (each with its own context and output buffer); 1 = strictly one at a time")
     ap.add_argument("--force-exchange", action="store_true",
@@ -424,7 +427,7 @@ def main():
     # CUs for the slowest workgroup of every launch -- ~3 % -- goes).  A launch's own duration then says nothing (two
     # launches are always under way), which is why the timed region above keeps the scans apart.
     overlap_value = None
-    if not multi and len(lanes) > 1 and not args.overlap_scans:
+    if args.measure_overlap and not multi and len(lanes) > 1 and not args.overlap_scans:
         args.overlap_scans = True
         n2 = min(args.steps, 100)
         for i in range(4):
