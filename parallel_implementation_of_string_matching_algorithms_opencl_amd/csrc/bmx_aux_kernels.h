@@ -43,7 +43,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
                                                               uint32_t *bucket_overflow, uint64_t *status,
                                                               uint64_t *host_status, uint64_t seq,
                                                               uint64_t *multi_first, uint32_t multi_threads_per_pattern,
-                                                              const uint8_t *text, uint64_t text_n)
+                                                              const uint8_t *text, uint64_t text_n, uint32_t expect_tiles)
 {
     __shared__ uint32_t wave_total[ORDER_THREADS / 64];
     __shared__ uint32_t seen[8]; // byte values among 4 x 256 bytes of the text just scanned (host_status[6]: see text_sigma, bmx_shim.hip)
@@ -58,7 +58,9 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
         for (uint32_t c = 0; c < 4; ++c) sample[c] = tid < len ? text[(text_n - len) / 3 * c + tid] : text[0];
     }
     const unsigned long long total = *count;
-    const uint32_t scan_err = bucket_overflow[1]; // raised by finish_parked (bmx_scan_common.h): the list is incomplete
+    // raised by finish_parked (bmx_scan_common.h): the list is incomplete; or a stolen-tail scan (scan_kernel MODE 12) whose
+    // workgroups did not walk every tile exactly once between them -- cannot happen, and must never pass for an answer
+    const uint32_t scan_err = bucket_overflow[1] | (expect_tiles != 0 && bucket_overflow[4] != expect_tiles ? 2u : 0u);
     const uint32_t dense = bucket_overflow[2];    // raised by a workgroup that met a dense tile: the list comes from the fill pass
     const bool ordered = out != nullptr && *bucket_overflow == 0 && dense == 0 && total <= cap; // block-uniform
 
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
         bucket_overflow[1] = 0;
         bucket_overflow[2] = 0;
         bucket_overflow[3] = 0; // (the ticket counter of scan_kernel MODE 12)
+        bucket_overflow[4] = 0; // (... and its count of tiles walked)
         // the host polls host_status[2] (pinned, fine-grained) for this search's sequence number
         host_status[0] = total;
         host_status[1] = needs_sort;

@@ -488,6 +488,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             }
         }
     }
+    if constexpr (STEAL)
+        if (tid == 0) atomicAdd(a.bucket_overflow + 4, it); // tiles this workgroup walked: the ordering kernel wants the sum to be all of them
     if (wg_dense && tid == 0) { // tell bmx_search_device_finish, and add what the dense tiles held to the total
         a.bucket_overflow[2] = 1u;
         (void)__hip_atomic_fetch_add(a.count, dense_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -81,6 +81,7 @@ struct Variant {
     void (*fill_short)(const bmx::ScanArgs);
     void (*fill_count)(const bmx::ScanArgs); // the fill pass's first launch (tile counts)
     void (*fill_count_short)(const bmx::ScanArgs);
+    bool steal = false; // the main kernel hands its last tiles out by ticket (scan_kernel MODE 12): the ordering kernel checks the tile count
 };
 
 // The slot numbers are stable (tools/ and the notes in DESIGN.md refer to them), but the PRODUCT library
@@ -112,11 +113,11 @@ struct Variant {
 #define BMX_TILE_S(B, S, AUX, W) \
     {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 3 ? 4 : ((W) == 10 ? 8 : 0), bmx::scan_kernel<B, S, AUX, 12, W>, \
      bmx::scan_kernel<B, S, AUX, 0, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>, \
-     bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>}
+     bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>, true}
 #define BMX_TILE_W32(B, S, AUX, MODE, W) /* 32 waves per CU: the 80-SGPR build */ \
     {0, B, S, 2, 0, 0, (MODE) == 5, (W) == 3, (W) == 3 ? 4 : 0, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, MODE, 6, 0>, \
      (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 0> : nullptr, (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 6> : nullptr, \
-     (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 10, 0> : nullptr, (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 10, 6> : nullptr}
+     (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 10, 0> : nullptr, (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 10, 6> : nullptr, (MODE) == 12}
 #define BMX_RING(B, S, AUX, SKIP, MODE) BMX_RING_P(B, S, AUX, (SKIP) ? 2 : 0, MODE, 0)
 #define BMX_RING_P(B, S, AUX, W, MODE, P) \
     {2, B, S, 3, 0, 0, (MODE) == 5, (W) == 10, (W) == 10 ? 8 : 0, bmx::scan_ring_kernel<B, S, AUX, W, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, 0, MODE, P>, nullptr, nullptr, nullptr, nullptr}
@@ -454,7 +455,7 @@ int bmx_ctx_create(int device, bmx_ctx **out)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_bucket_cnt, bmx::ORDER_BUCKETS * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipMalloc(&ctx->d_bucket_store, (size_t)bmx::ORDER_BUCKETS * bmx::ORDER_BUCKET_CAP * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, 4 * sizeof(uint32_t)); // {bucket overflow, scan error, dense, -}
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, 8 * sizeof(uint32_t)); // {bucket overflow, scan error, dense, ticket counter, tiles walked (stolen-tail kernels), -, -, -}
     if (e == hipSuccess) e = hipMalloc(&ctx->d_status, 4 * sizeof(uint64_t));
     if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 8 * sizeof(uint64_t), hipHostMallocMapped); // [4], [5]: alphabet sample {sigma, seq}; [6]: order_kernel's sample
     if (e == hipSuccess) {
@@ -578,13 +579,14 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     if (!ctx->armed) { // first use, or a previous enqueue failed half way: zero the device counters
         HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(ctx->d_bucket_cnt, 0, bmx::ORDER_BUCKETS * sizeof(uint32_t), stream));
-        HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, 4 * sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, 8 * sizeof(uint32_t), stream));
     }
     ctx->armed = false;
 
     // windows that fit: starts 0 .. n-m; of those the caller owns [0, n_own)
     const uint64_t n_starts = n < (uint64_t)m ? 0 : std::min<uint64_t>(n - (uint64_t)m + 1, n_own);
     uint64_t *out = capacity ? d_match_positions : nullptr;
+    uint32_t expect_tiles = 0; // stolen-tail kernels: the tiles the workgroups must have walked between them (order_kernel checks)
 
     if (n_starts > 0) {
         bmx::ScanArgs a;
@@ -679,6 +681,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(v.block), lds, stream, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
+        if (v.steal && m >= 4) expect_tiles = (uint32_t)(a.tile_end - a.tile_begin);
         ctx->n_timed++;
         ctx->timed = true;
         ctx->last_args = a;
@@ -691,7 +694,8 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     // ascending list from the position buckets, {count, needs_sort} for the host, counters re-armed
     hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, out, capacity, ctx->d_count,
                        ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status, ctx->h_status_dev,
-                       ++ctx->seq, (uint64_t *)nullptr, 1u, ctx->auto_walker && !getenv("BMX_NO_TEXT_SAMPLE") ? (const uint8_t *)d_text : nullptr, n);
+                       ++ctx->seq, (uint64_t *)nullptr, 1u, ctx->auto_walker && !getenv("BMX_NO_TEXT_SAMPLE") ? (const uint8_t *)d_text : nullptr, n,
+                       expect_tiles);
     ctx->last_text = d_text, ctx->last_text_n = n;
     HIPCHK(hipGetLastError());
     ctx->armed = true;
@@ -733,7 +737,10 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
         for (auto &e : ctx->sampled)
             if (e.ptr == ctx->last_text && e.n == ctx->last_text_n) e.sigma = (int)ctx->h_status[6];
     if (ctx->h_status[3] != 0) { // finish_parked (bmx_scan_common.h): matches were dropped, the list is not the answer
-        set_err("scan kernel: a workgroup waited longer than its bound for a slot reservation; result discarded");
+        if (ctx->h_status[3] & 2)
+            set_err("scan kernel: the workgroups did not walk every tile exactly once between them (stolen tail); result discarded");
+        else
+            set_err("scan kernel: a workgroup waited longer than its bound for a slot reservation; result discarded");
         if (n_matches) *n_matches = 0;
         return BMX_ERR_HIP;
     }
@@ -895,7 +902,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     if (!ctx->armed) {
         HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(ctx->d_bucket_cnt, 0, bmx::ORDER_BUCKETS * sizeof(uint32_t), stream));
-        HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, 4 * sizeof(uint32_t), stream));
+        HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, 8 * sizeof(uint32_t), stream));
     }
     ctx->armed = false;
     if (getenv("BMX_MULTI_NO_QGRAM")) qmask = 0; // (tools/: A/B runs)
@@ -975,7 +982,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     ctx->last_fillable = false;
     hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, d_match_positions, capacity, ctx->d_count,
                        ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status, ctx->h_status_dev, ++ctx->seq,
-                       ctx->d_multi_first, a.bucket_stride / 8u, (const uint8_t *)d_text, n);
+                       ctx->d_multi_first, a.bucket_stride / 8u, (const uint8_t *)d_text, n, 0u);
     ctx->last_text = d_text, ctx->last_text_n = n;
     HIPCHK(hipGetLastError());
     ctx->armed = true;
