@@ -12,7 +12,7 @@
 //   hits --(wave __ballot / popcount ranks into an LDS parking buffer; ONE global atomic per workgroup and tile,
 //           deferred by a tile; dense tiles are only counted and written by the fill pass)--> HBM list
 //
-//  * A workgroup owns tiles t = blockIdx, blockIdx + grid, ...; tile t is the
+//  * A workgroup owns tiles t = blockIdx, blockIdx + grid, ... (MODE 12: up to a pool of last tiles); tile t is the
 //    TILE = BLOCK*SEG window starts [t*TILE, (t+1)*TILE) and needs the bytes
 //    [t*TILE, (t+1)*TILE + m-1): the (m-1)-byte overlap lives only in LDS, HBM
 //    sees each text byte once plus the halo (<= 0.3 % at m = 99).
@@ -38,7 +38,9 @@ namespace bmx {
 // after an exclusive scan of those counts -- write every tile's matches in ascending order at tile_base[tile] +
 // (exclusive scan of the lanes' counts), each tile walked twice.
 // AUX: cache-policy bits of the DMA (0 default, 2 = nt: the text is read once).
-// MODE 0 is the product; MODE 1 (DMA only, no walkers) and MODE 2 (walkers only:
+// MODE 0 is the product, MODE 12 the product with static tile shares + a stolen tail (the last tiles of every workgroup
+// come out of a pool, by ticket: the 8-gram and 4-gram kernels and the byte-wise kernel for long patterns);
+// MODE 11: every workgroup a contiguous run of tiles (experiment); MODE 1 (DMA only, no walkers) and MODE 2 (walkers only:
 // each workgroup loads its first two tiles and keeps re-walking them) exist for
 // timing the two halves alone and return wrong match lists.
 // WALK 0: byte-wise walker, any m.  WALK 2: skip-loop walker, needs m >= 4.  WALK 3: 4-gram
@@ -48,6 +50,7 @@ namespace bmx {
 // WALK 7 / 8: skip loop by quad-SAD on the pattern's last 4 (m >= 4) / 8 (m >= 8) bytes, match and shift by the
 // reference's rule at every stop (walk_lane_sad, bmx_scan_common.h): no dependent LDS chain.
 // WALK 20: K patterns in one pass (bmx_search_device_multi): the byte-wise walker once per pattern over each tile.
+// WALK 21: the same with the 8-gram walker for the patterns of a.multi_qmask (their shift tables behind the blob).
 // WALK 9: byte-wise walker behind a 128-bit set of the pattern's characters in scalar registers (the shift table in
 // LDS is only read for windows that end in a character of the pattern).  WALK 10: 8-gram walker, m >= 8.
 // (A WALK 1 that fetched the last four characters with one unaligned ds_read_b32 was
