@@ -278,14 +278,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         // looked at after it: a read that is waited for on the spot costs every wave ~150 cycles per tile)
         uint32_t parked_now = 0;
         if (MODE != 1 && tb.stage_cap != 0 && it != 0) parked_now = *park_cnt((it & 1u) ^ 1u);
-        if (issue_now && !issue_late) issue_tile(tn, cur ? buf0 : buf1);
         if constexpr (ST) {
-            // the tile AFTER tn comes out of the pool (tn is the last of the static share, or a pool tile itself): ask now
+            // the tile AFTER tn comes out of the pool (tn is the last of the static share, or a pool tile itself): ask now,
+            // IN FRONT of the DMA issue -- the issue holds a wave for 1500-3000 cycles, a head start the request can use
             if (tn != NO_TILE && !pool_dry && tn + gridDim.x >= steal_begin) {
                 if (tid == 0) ticket = atomicAdd(a.bucket_overflow + 3, 1u);
                 ticket_pending = true;
             }
         }
+        if (issue_now && !issue_late) issue_tile(tn, cur ? buf0 : buf1);
         // Matches parked while the PREVIOUS tile was walked: reserve their slots now (one global atomic by
         // one thread, not waited for; after the DMA issue, which must not wait for the LDS read here), park
         // this tile's matches in the other buffer meanwhile.
