@@ -206,7 +206,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         // (measured, 4 GiB, median of 15 interleaved launches, ms: 8-gram walker on ACGT, m = 64: no pool 0.674, 3 tiles per
     // workgroup 0.669, 8: 0.657, 16: 0.643, 32: 0.645, 64: 0.677; byte-wise walker on printable text, m = 16: no pool
     // 0.651, 3: 0.651, 8: 0.648, 16: 0.656)
-    constexpr uint64_t STEAL_RESERVE = WALK == 10 ? 16 : 8, NO_TILE = ~0ull;
+    // (... byte-wise, m = 32: 8 and 16 tie at 0.633 against 0.648; m = 64: 0.667 without, 0.661 with 8, 0.643 with 16: the
+    // byte-wise kernel only runs this way from m = 28 on)
+    constexpr uint64_t STEAL_RESERVE = WALK == 3 ? 8 : 16, NO_TILE = ~0ull;
     uint64_t steal_begin = 0, t_prev = NO_TILE, tn_steal = NO_TILE;
     uint32_t ticket = 0;          // thread 0: the pending request's result
     bool ticket_pending = false;  // uniform: a request is under way (its result is read at the next loop top)

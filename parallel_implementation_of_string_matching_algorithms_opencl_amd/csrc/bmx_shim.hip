@@ -363,7 +363,7 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
     if (large_alphabet) { // sparse by nature (9^-4 and less)
         if (sigma > 0 && m <= 11 && distinct > 1) return 2; // short patterns: long walks, 32 waves per CU hide them better
         // (4 GiB printable text, byte-wise walker, ms without / with the stolen tail: m = 16: 0.651 / 0.653, m = 24: 0.643 / 0.640,
-        // m = 32: 0.672 / 0.649, m = 48: 0.693 / 0.675, m = 64: 0.680 / 0.655)
+        // m = 32: 0.648 / 0.633, m = 64: 0.668 / 0.643)
         if (m >= 28 && fits(VARIANT_BIG_TILE_STEAL)) return VARIANT_BIG_TILE_STEAL;
         return fits(VARIANT_BIG_TILE) ? VARIANT_BIG_TILE : 0;
     }
