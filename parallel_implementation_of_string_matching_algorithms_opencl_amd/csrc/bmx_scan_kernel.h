@@ -215,7 +215,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     bool pool_dry = false;        // uniform: the counter has run past the pool
     if constexpr (STEAL) {
         const uint64_t per_wg = (a.tile_end - a.tile_begin) / gridDim.x;
-        steal_begin = per_wg > 2 * STEAL_RESERVE ? a.tile_begin + (per_wg - STEAL_RESERVE) * gridDim.x : a.tile_end; // (short texts: no pool)
+        // at most STEAL_RESERVE tiles per workgroup and at most ~8 % of its tiles (a pool of 16 out of the 57 tiles a
+        // workgroup has of 1 GiB cost the skip-loop kernel 17 %); texts of a few tiles per workgroup: no pool
+        const uint64_t reserve = per_wg / 12 < STEAL_RESERVE ? per_wg / 12 : STEAL_RESERVE;
+        steal_begin = reserve >= 2 ? a.tile_begin + (per_wg - reserve) * gridDim.x : a.tile_end;
     }
     uint32_t it = 0; // tiles walked so far by this workgroup
     uint32_t seen[2] = {0, 0}; // the parking buffers' counts as of their last collection

@@ -115,9 +115,9 @@ struct Variant {
      bmx::scan_kernel<B, S, AUX, 0, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>, \
      bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>, true}
 #define BMX_TILE_W32(B, S, AUX, MODE, W) /* 32 waves per CU: the 80-SGPR build */ \
-    {0, B, S, 2, 0, 0, (MODE) == 5, (W) == 3, (W) == 3 ? 4 : 0, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, MODE, 6, 0>, \
-     (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 0> : nullptr, (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 9, 6> : nullptr, \
-     (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 10, 0> : nullptr, (MODE) == 0 ? bmx::scan_kernel<B, S, AUX, 10, 6> : nullptr, (MODE) == 12}
+    {0, B, S, 2, 0, 0, (MODE) == 5, (W) == 3, (W) == 3 ? 4 : 0, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, (MODE) == 12 ? 0 : (MODE), 6, 0>, \
+     (MODE) == 0 || (MODE) == 12 ? bmx::scan_kernel<B, S, AUX, 9, 0> : nullptr, (MODE) == 0 || (MODE) == 12 ? bmx::scan_kernel<B, S, AUX, 9, 6> : nullptr, \
+     (MODE) == 0 || (MODE) == 12 ? bmx::scan_kernel<B, S, AUX, 10, 0> : nullptr, (MODE) == 0 || (MODE) == 12 ? bmx::scan_kernel<B, S, AUX, 10, 6> : nullptr, (MODE) == 12}
 #define BMX_RING(B, S, AUX, SKIP, MODE) BMX_RING_P(B, S, AUX, (SKIP) ? 2 : 0, MODE, 0)
 #define BMX_RING_P(B, S, AUX, W, MODE, P) \
     {2, B, S, 3, 0, 0, (MODE) == 5, (W) == 10, (W) == 10 ? 8 : 0, bmx::scan_ring_kernel<B, S, AUX, W, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, 0, MODE, P>, nullptr, nullptr, nullptr, nullptr}
@@ -214,7 +214,7 @@ const Variant g_variants[] = {
     BMX_TILE_S(1024, 76, 2, 0),                        // 79: PRODUCT -- variant 29 with a stolen tail (scan_kernel MODE 12): long patterns on large alphabets
     BMX_EXP(BMX_TILE_F(1024, 76, 2, 10)),              // 80: variant 53 without its stolen tail (static shares only)
     BMX_EXP(BMX_TILE_F(1024, 76, 2, 3)),               // 81: variant 54 (4-gram walker) without its stolen tail
-    BMX_EXP(BMX_TILE_W32(1024, 36, 2, 12, 2)),         // 82: variant 2 (skip loop, two workgroups per CU) with a stolen tail: nothing gained (printable m = 8: 0.750 vs 0.742 ms)
+    BMX_TILE_W32(1024, 36, 2, 12, 2),                  // 82: PRODUCT -- variant 2 (skip loop, two workgroups per CU) with a stolen tail: large alphabets, m = 9..12
 };
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
@@ -327,6 +327,7 @@ uint32_t lds_bytes_for(const Variant &v, int32_t m);
 
 constexpr int VARIANT_QGRAM4 = 54;   // 4-gram walker, 76 KiB tiles
 constexpr int VARIANT_QGRAM8 = 53;   // 8-gram walker, 76 KiB tiles
+constexpr int VARIANT_SKIP_STEAL = 82;     // skip loop on 36 KiB tiles, two workgroups per CU, static shares + a stolen tail
 constexpr int VARIANT_BIG_TILE_STEAL = 79; // ... with a stolen tail: the shorter the walk, the more a launch waits for its slowest workgroup
 constexpr int VARIANT_BIG_TILE = 29; // 76 KiB tiles: +2 % on large alphabets, but room for 512 parked matches per tile only
 
@@ -361,7 +362,11 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
     auto fits = [&](int vi) { return lds_bytes_for(g_variants[vi], m) <= LDS_PER_CU; };
     const bool large_alphabet = sigma > 0 ? sigma > 8 : distinct > 8;
     if (large_alphabet) { // sparse by nature (9^-4 and less)
-        if (sigma > 0 && m <= 11 && distinct > 1) return 2; // short patterns: long walks, 32 waves per CU hide them better
+        // short patterns: long walks, 32 waves per CU hide them better (4 GiB printable text, ms, byte-wise 76 KiB / skip loop
+        // 36 KiB / the latter with a stolen tail: m = 8: - / 0.742 / 0.750, m = 10: 0.768 / 0.726 / 0.690, m = 12: 0.727 / 0.752 /
+        // 0.697, m = 13: 0.703 / 0.775 / 0.714, m = 15: 0.685 / 0.766 / 0.715)
+        if (sigma > 0 && m <= 8 && distinct > 1) return 2;
+        if (sigma > 0 && m <= 12 && distinct > 1) return VARIANT_SKIP_STEAL;
         // (4 GiB printable text, byte-wise walker, ms without / with the stolen tail: m = 16: 0.651 / 0.653, m = 24: 0.643 / 0.640,
         // m = 32: 0.648 / 0.633, m = 64: 0.668 / 0.643)
         if (m >= 28 && fits(VARIANT_BIG_TILE_STEAL)) return VARIANT_BIG_TILE_STEAL;

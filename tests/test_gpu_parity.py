@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 # bmx_shim.hip: the slots built into libbmx.so.  Every other slot (losing schedules, timing-only kernels whose
 # match lists are not valid) exists in libbmx_exp.so only and is refused by bmx_set_variant here.
-PRODUCT_VARIANTS = [0, 1, 2, 24, 25, 29, 53, 54, 79]
+PRODUCT_VARIANTS = [0, 1, 2, 24, 25, 29, 53, 54, 79, 82]
 QGRAM_VARIANTS = [24, 25, 53, 54]  # 4-gram and 8-gram walkers
 
 
