@@ -649,7 +649,9 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         uint64_t nblocks = a.tile_end - a.tile_begin; // kind 0: one tile per workgroup at a time
         if (v.kind == 1) nblocks = (nblocks + v.block / 64 - 1) / (v.block / 64); // one piece per wave
         const uint64_t max_grid = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(nblocks, max_grid);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(nblocks, max_grid);
+        if (const char *g = getenv("BMX_MAX_GRID")) // tests: few workgroups, so that a text of a few MiB gives each of them tiles enough for a stolen tail
+            grid = std::min<uint32_t>(grid, (uint32_t)std::max(1, atoi(g)));
 
         // dense results: the scan counts per tile, bmx_search_device_finish runs the fill pass of this geometry
         auto fill = m >= 4 ? v.fill : v.fill_short;

@@ -570,6 +570,43 @@ def test_walker_follows_the_texts_alphabet(built, port):
                 assert c.geometry(m)["tile_bytes"] == tile_bytes, (m, c.geometry(m))
 
 
+def test_stolen_tail_on_small_texts(built, port, monkeypatch):
+    """The kernels that hand their last tiles out by ticket (variants 53, 54, 79, 82) only do so when a workgroup has
+    two dozen tiles and more -- half a GiB of text on 256 CUs, which only the full-size tests reach.  With the grid
+    capped at a few workgroups (BMX_MAX_GRID, a test hook) texts of a few MiB go through the pool: sparse, clustered
+    and dense results, a misaligned pointer, shard semantics, a tile count that is no multiple of anything, and twice
+    in a row on one context (the ticket counter is re-armed by the ordering kernel) -- against the oracle."""
+    import torch
+
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import host
+
+    rng = np.random.default_rng(1212)
+    out = torch.empty(1 << 22, dtype=torch.int64, device="cuda")
+    for grid in ("3", "5"):
+        monkeypatch.setenv("BMX_MAX_GRID", grid)
+        with host.Context(0) as c:
+            for variant, alpha, m in ((53, 4, 24), (53, 2, 64), (54, 4, 7), (79, 60, 40), (79, 4, 30), (82, 60, 10), (82, 60, 12)):
+                n = int(rng.integers(9_000_000, 12_000_000))
+                text = (rng.integers(0, alpha, n) + 65).astype(np.uint8)
+                pat = text[12345:12345 + m].copy()
+                for p in rng.integers(0, n - m, 300):
+                    text[p:p + m] = pat
+                text[n // 2:n // 2 + 3000] = pat[0]  # a stretch that clusters or densifies the matches of short shifts
+                pat = pat.tobytes()
+                d_all = torch.from_numpy(np.concatenate([np.zeros(7, np.uint8), text])).cuda()
+                c.set_variant(variant)
+                for rep in range(2):
+                    pos, total = c.search_device(d_all[7:], pat, out=out)
+                    want = port.search(text, pat)
+                    assert total == want.size and np.array_equal(pos.cpu().numpy().astype(np.uint64), want), (grid, variant, alpha, m, rep)
+                lo, own = 1_000_003, 6_000_000
+                pos, total = c.search_device(d_all[7 + lo:7 + lo + own + m - 1], pat, n_own=own, base_offset=lo, out=out)
+                want = port.search(text, pat)
+                want = want[(want >= lo) & (want < lo + own)]
+                assert total == want.size and np.array_equal(pos.cpu().numpy().astype(np.uint64), want), (grid, variant, "shard")
+    monkeypatch.delenv("BMX_MAX_GRID")
+
+
 def test_short_patterns_in_a_shard_view(ctx, port):
     """Patterns of 1-3 bytes are tested sixteen window starts at a time, a wave piece of the tile per wave
     (ShortTile): the edges of what a call reports -- the first window start (misaligned pointer), the end of the owned
