@@ -248,6 +248,7 @@ struct bmx_ctx {
     uint64_t *d_tile_base = nullptr;       // their exclusive scan
     uint32_t *d_wave_count = nullptr;      // 1-3-byte patterns: matches per wave piece of every tile (block / 64 words per tile)
     uint64_t tile_cap = 0;                 // tiles both arrays have room for
+    int multi_attr[2] = {0, 0};            // dynamic-LDS limit set for the two multi-pattern kernels on this device
     uint8_t *d_multi = nullptr;            // bmx_search_device_multi: the patterns' tables (one blob) and first[]
     uint64_t *d_multi_first = nullptr;
     bmx::ScanArgs last_args;               // the last scan launch (the fill pass re-runs its geometry)
@@ -973,10 +974,9 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
         ctx->armed = true;
         return one_by_one();
     }
-    static int multi_attr[2] = {0, 0};
-    if (multi_attr[with_q] < (int)lds) {
+    if (ctx->multi_attr[with_q] < (int)lds) { // (per context = per device: a function attribute is the device's)
         HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        multi_attr[with_q] = (int)lds;
+        ctx->multi_attr[with_q] = (int)lds;
     }
     const uint32_t grid = (uint32_t)std::min<uint64_t>(a.tile_end - a.tile_begin, (uint64_t)ctx->num_cu);
     const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
