@@ -31,6 +31,9 @@ events recorded around that kernel on its launch stream) and, at N = 1,
 `cpu_baseline` (the reference's serial CPU Boyer-Moore -- oracle/_ref when it
 is present, else the C restatement -- timed on this host over the same text,
 which doubles as the full-size bit-exactness check of the GPU match list).
+Before the --warmup steps the device's clocks are ramped up with 40 untimed
+searches (--ramp-up; the first ~10 launches after the set-up's idle time run
+5-10 % slower); the line reports it as config.ramp_up_searches.
 The timed region keeps the scan kernels of consecutive searches apart, so that a
 launch's duration is the kernel's; what the same stream of searches reaches when
 they may share the GPU is measured behind it with --measure-overlap and reported as
@@ -63,6 +66,8 @@ def parse_args(argv=None):
                     help="let the scan kernels of consecutive searches share the GPU (a CU holds one workgroup, so search "
                          "k+1's workgroups start wherever search k's are done): higher whole-job throughput; a launch's own "
                          "duration then says nothing, so the roofline object is not comparable -- not the default")
+    ap.add_argument("--ramp-up", type=int, default=40,
+                    help="untimed searches before the --warmup steps, for the device's clocks (default 40 = ~26 ms; 0: none)")
     ap.add_argument("--measure-overlap", action="store_true",
                     help="behind the timed region, time the same searches once more with overlapping scans and report it as "
                          "config.whole_job_GBps_if_scans_may_overlap (off by default: its launches would be in every profile of this command)")
@@ -387,6 +392,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Before anything is counted, whatever --warmup says: (1) one search per lane -- the first search of a context on a
+    # text looks at the text's alphabet (one wait of ~20 us) and sets the kernel's LDS limit; (2) the device's clocks: the
+    # first ~10 launches after the idle time of the set-up run 5-10 % slower (0.71, 0.72, 0.71, 0.70, 0.69, 0.68, 0.67,
+    # 0.65 ms ... on config 2), which with --steps 20 --warmup 5 would be a fifth of the timed region.  --ramp-up 0 turns
+    # it off; the line reports it (config.ramp_up_searches).
+    for i in range(max(len(lanes), args.ramp_up)):
+        step(i)
+    fence()
     for i in range(args.warmup):
         step(i)
     fence()
@@ -452,7 +465,7 @@ def main():
                   ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process"),
         "config": {"workload": spec.name, "text_bytes_total": spec.n, "text_bytes_per_gpu": n_own,
                    "pattern_bytes": m, "alphabet": "printable-95" if spec.kind == 0 else "ACGT",
-                   "matches": int(result.size), "searches_in_flight": len(lanes), "scans_overlap": bool(args.overlap_scans),
+                   "matches": int(result.size), "searches_in_flight": len(lanes), "scans_overlap": bool(args.overlap_scans), "ramp_up_searches": max(len(lanes), args.ramp_up),
                    "whole_job_GBps_if_scans_may_overlap": None if overlap_value is None else round(overlap_value, 1), "sharding": f"{world} contiguous shard(s) + {m - 1} B halo",
                    "exchange": ("REHEARSAL on one GPU, gloo via host" if rehearse else
                                 "RCCL all-gather of [count|offsets] slots") if multi else "none",
