@@ -134,21 +134,23 @@ __global__ void sa_copy_out(const uint32_t *idx_sorted, uint32_t n, int32_t *sa)
 #if SA_EXP & 8
 __device__ unsigned long long sa_dbg[8]; // phase times of sa_segsort_kernel, summed over workgroups (10 ns units), and their number
 #endif
-constexpr uint32_t SEG_W = 8192, SEG_T = 1024, SEG_PER = SEG_W / SEG_T;
+constexpr uint32_t SEG_W = 8192, SEG_LOGK = 3, SEG_PER = 1u << SEG_LOGK, SEG_T = SEG_W / SEG_PER; // keys per thread: 8 (16 = 512 threads, 24 sorting
+                                                                                                        // rounds instead of 32, measured: 3.17 ms against 2.70 for the 2 MiB corpus -- half the waves hide less of the gathers)
+static_assert(SEG_LOGK == 3 || SEG_LOGK == 4, "");
 
 // Slot s of the window lives at LDS word s + s / 8: a thread's 8 consecutive slots (and the 8 slots 2^sh apart that the
 // sorting rounds below give it) then fall into different banks instead of 16 lanes onto one.
-__device__ __forceinline__ uint32_t seg_pos(uint32_t s) { return s + (s >> 3); }
+__device__ __forceinline__ uint32_t seg_pos(uint32_t s) { return s + (s >> SEG_LOGK); }
 
 // Bitonic sort of the 8192 keys of a window, ascending, in the form whose comparators all point the same way: phase
 // p = 1..13 turns sorted runs of 2^(p-1) into sorted runs of 2^p with a MIRROR step (slot s against s ^ (2^p - 1)) and
 // then steps at distances 2^(p-2) ... 1 (s against s ^ distance); the smaller key always goes to the lower slot, so
 // a compare-exchange is one 64-bit compare and four selects.  Phases 1-3 happen in registers before the keys are
-// written (sort8: a thread builds 8 consecutive slots).  From phase 4 on a round = one LDS exchange: a thread takes
+// written (sort_own: a thread builds 8 consecutive slots).  From phase 4 on a round = one LDS exchange: a thread takes
 // the 8 keys whose slots differ in bits sh+2..sh and applies up to three consecutive steps (distances 4, 2, 1 << sh)
 // to them in registers.  A round that begins with the mirror step takes, for its upper four registers, the mirror
 // images of the lower four: that set is closed under the following steps too, only its slot order is reversed.
-// 32 rounds for the 85 steps behind sort8.
+// 32 rounds for the 85 steps behind sort_own.
 __device__ __forceinline__ void seg_cx(uint64_t &lo, uint64_t &hi)
 {
     const uint64_t a = lo, b = hi;
@@ -159,82 +161,90 @@ __device__ __forceinline__ void seg_cx(uint64_t &lo, uint64_t &hi)
     hi = lt ? b2 : a;
 }
 
-__device__ __forceinline__ void sort8(uint64_t (&r)[8]) // 19 comparators
+// a thread's SEG_PER consecutive slots in registers: Batcher's merge exchange (19 comparators for 8 keys, 63 for 16)
+__device__ __forceinline__ void sort_own(uint64_t (&r)[SEG_PER])
 {
-    seg_cx(r[0], r[2]), seg_cx(r[1], r[3]), seg_cx(r[4], r[6]), seg_cx(r[5], r[7]);
-    seg_cx(r[0], r[4]), seg_cx(r[1], r[5]), seg_cx(r[2], r[6]), seg_cx(r[3], r[7]);
-    seg_cx(r[0], r[1]), seg_cx(r[2], r[3]), seg_cx(r[4], r[5]), seg_cx(r[6], r[7]);
-    seg_cx(r[2], r[4]), seg_cx(r[3], r[5]);
-    seg_cx(r[1], r[4]), seg_cx(r[3], r[6]);
-    seg_cx(r[1], r[2]), seg_cx(r[3], r[4]), seg_cx(r[5], r[6]);
+#pragma unroll
+    for (uint32_t p = 1; p < SEG_PER; p *= 2)
+#pragma unroll
+        for (uint32_t k = p; k >= 1; k /= 2)
+#pragma unroll
+            for (uint32_t j = k % p; j + k < SEG_PER; j += 2 * k)
+#pragma unroll
+                for (uint32_t i = 0; i < k; ++i)
+                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) seg_cx(r[i + j], r[i + j + k]);
 }
 
-// STEPS: the top 1, 2 or 3 of the distances 4, 2, 1 << sh; MIRROR: the first of them is the phase's mirror step
+// STEPS: the top STEPS of the distances (SEG_PER / 2 ... 2, 1) << sh; MIRROR: the first of them is the phase's mirror step
 // (low_mask = 2^p - 1).
 // Slots outside [lo, hi) hold keys that are in place already and below (above) every key inside: a comparator with
 // one of them changes nothing, so a thread none of whose slots lies inside has nothing to do in this round.
 template <int STEPS, bool MIRROR>
 __device__ __forceinline__ void seg_sort_round(uint64_t *key, uint32_t tid, uint32_t sh, uint32_t low_mask, uint32_t lo, uint32_t hi)
 {
-    const uint32_t base = ((tid >> sh) << (sh + 3)) | (tid & ((1u << sh) - 1u));
+    constexpr uint32_t K = SEG_PER, HALF = K / 2;
+    constexpr int TOP = (int)SEG_LOGK - 1;
+    const uint32_t base = ((tid >> sh) << (sh + SEG_LOGK)) | (tid & ((1u << sh) - 1u));
     {
-        const uint32_t top = base | ((MIRROR ? 3u : 7u) << sh); // the thread's lowest slot is `base`, or the mirror image of `top`
+        const uint32_t top = base | ((MIRROR ? HALF - 1 : K - 1) << sh); // the thread's lowest slot is `base`, or the mirror image of `top`
         const uint32_t lowest = MIRROR ? min(base, top ^ low_mask) : base, highest = MIRROR ? max(top, base ^ low_mask) : top;
         if (highest < lo || lowest >= hi) return;
     }
-    uint32_t pos[8];
-    uint64_t r[8];
+    uint32_t pos[K];
+    uint64_t r[K];
 #pragma unroll
-    for (uint32_t q = 0; q < 8; ++q) {
-        const uint32_t s = MIRROR && (q & 4u) ? (base | ((q ^ 4u) << sh)) ^ low_mask : base | (q << sh);
+    for (uint32_t q = 0; q < K; ++q) {
+        const uint32_t s = MIRROR && (q & HALF) ? (base | ((q ^ HALF) << sh)) ^ low_mask : base | (q << sh);
         pos[q] = seg_pos(s);
         r[q] = key[pos[q]];
     }
 #pragma unroll
-    for (int step = 2; step > 2 - STEPS; --step) {
+    for (int step = TOP; step > TOP - STEPS; --step) {
         const uint32_t d = 1u << step;
 #pragma unroll
-        for (uint32_t q = 0; q < 8; ++q) {
+        for (uint32_t q = 0; q < K; ++q) {
             if ((q & d) != 0) continue;
-            if (MIRROR && step < 2 && (q & 4u)) seg_cx(r[q | d], r[q]); // mirror images: register order is the reverse of slot order
+            if (MIRROR && step < TOP && (q & HALF)) seg_cx(r[q | d], r[q]); // mirror images: register order is the reverse of slot order
             else seg_cx(r[q], r[q | d]);
         }
     }
 #pragma unroll
-    for (uint32_t q = 0; q < 8; ++q) key[pos[q]] = r[q];
+    for (uint32_t q = 0; q < K; ++q) key[pos[q]] = r[q];
 }
 
-// the window holds sorted runs of 8 (sort8); phases 4..13
+// the window holds sorted runs of SEG_PER (sort_own); phases SEG_LOGK + 1 .. 13
 __device__ __forceinline__ void seg_sort(uint64_t *key, uint32_t tid, uint32_t lo, uint32_t hi)
 {
-    // A round with sh <= 6 is WAVE-LOCAL: the 64 threads of wave w take exactly the slots [512 w, 512 w + 512) (and a
-    // mirror step of a phase p <= 9 stays inside them), so between two such rounds no barrier is needed -- a wave's LDS
-    // instructions execute in order -- and the waves drift apart instead of meeting 32 times: 10 barriers are left
-    // (around the rounds with sh = 7 .. 10, and one at the end), and the rounds a wave skips are now time it gives
-    // to the others.
+    // A round with sh <= 6 is WAVE-LOCAL: the 64 threads of wave w take exactly the slots [64 SEG_PER w, 64 SEG_PER (w + 1))
+    // (and a mirror step of a phase that small stays inside them), so between two such rounds no barrier is needed -- a
+    // wave's LDS instructions execute in order -- and the waves drift apart instead of meeting after every round: the
+    // barriers left are those around the rounds with sh >= 7, and one at the end; the rounds a wave skips are time it
+    // gives to the others.
     bool prev_local = true; // (the keys in LDS were written by the threads that read them first)
     auto before = [&](uint32_t sh) {
         const bool local = sh <= 6;
         if (!(prev_local && local)) __syncthreads(); // (uniform)
         prev_local = local;
     };
+    constexpr uint32_t L = SEG_LOGK;
 #pragma unroll 1
-    for (uint32_t p = 4; (1u << p) <= SEG_W; ++p) {
+    for (uint32_t p = L + 1; (1u << p) <= SEG_W; ++p) {
         const uint32_t low_mask = (1u << p) - 1u;
-        uint32_t left = p - 3, a = p - 1; // steps at distances 2^a ... 8 go first, `left` of them
-        const uint32_t c = (left - 1) % 3 + 1;
-        before(a - 2);
-        if (c == 1) seg_sort_round<1, true>(key, tid, a - 2, low_mask, lo, hi);
-        else if (c == 2) seg_sort_round<2, true>(key, tid, a - 2, low_mask, lo, hi);
-        else seg_sort_round<3, true>(key, tid, a - 2, low_mask, lo, hi);
+        uint32_t left = p - L, a = p - 1; // steps at distances 2^a ... SEG_PER go first, `left` of them
+        const uint32_t c = (left - 1) % L + 1;
+        before(a - (L - 1));
+        if (c == 1) seg_sort_round<1, true>(key, tid, a - (L - 1), low_mask, lo, hi);
+        else if (c == 2) seg_sort_round<2, true>(key, tid, a - (L - 1), low_mask, lo, hi);
+        else if (c == 3) seg_sort_round<3, true>(key, tid, a - (L - 1), low_mask, lo, hi);
+        else seg_sort_round<(int)L, true>(key, tid, a - (L - 1), low_mask, lo, hi);
         a -= c, left -= c;
 #pragma unroll 1
-        for (; left != 0; left -= 3, a -= 3) {
-            before(a - 2);
-            seg_sort_round<3, false>(key, tid, a - 2, 0, lo, hi);
+        for (; left != 0; left -= L, a -= L) {
+            before(a - (L - 1));
+            seg_sort_round<(int)L, false>(key, tid, a - (L - 1), 0, lo, hi);
         }
         before(0);
-        seg_sort_round<3, false>(key, tid, 0, 0, lo, hi); // distances 4, 2, 1
+        seg_sort_round<(int)L, false>(key, tid, 0, 0, lo, hi); // distances SEG_PER / 2 ... 1
     }
     __syncthreads();
 }
@@ -265,12 +275,12 @@ __device__ __forceinline__ int block_excl_scan_max(int mine, int *red, uint32_t 
     return max(before, excl);
 }
 
-__global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *idx_in, const uint32_t *head_in,
+__global__ __launch_bounds__(SEG_T, SEG_LOGK == 3 ? 8 : 4) void sa_segsort_kernel(const uint32_t *idx_in, const uint32_t *head_in,
                                                            const uint32_t *rank_old, uint32_t n, uint32_t h, uint32_t SEG_C,
                                                            uint32_t *idx_out, uint32_t *head_out, uint32_t *rank_new,
                                                            uint32_t *counters, uint32_t *host_out)
 {
-    __shared__ uint64_t key[SEG_W + SEG_W / 8]; // (old group's head slot : 13 | second rank : 32 | slot before the sort : 13), at seg_pos(slot)
+    __shared__ uint64_t key[SEG_W + SEG_W / SEG_PER]; // (old group's head slot : 13 | second rank : 32 | slot before the sort : 13), at seg_pos(slot)
     __shared__ int red[SEG_T / 64];
     __shared__ uint32_t any_tie, first_head, own_end, n_heads, max_len;
     const uint32_t tid = threadIdx.x;
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
     unsigned long long tq[6];
     tq[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const uint32_t s0 = tid * SEG_PER; // this thread's 8 consecutive slots
+    const uint32_t s0 = tid * SEG_PER; // this thread's SEG_PER consecutive slots
     if (tid == 0) {
         any_tie = 0;
         first_head = SEG_W;
@@ -307,14 +317,17 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
     bool hf[SEG_PER];
     int gh[SEG_PER]; // slot of the head of the slot's group (-1: the group began before the window)
     int last = -1, first = -1;
-    {
-        const uint4 ta = *reinterpret_cast<const uint4 *>(st_idx + s0), tb = *reinterpret_cast<const uint4 *>(st_idx + s0 + 4);
-        const uint64_t hb = *reinterpret_cast<const uint64_t *>(st_head + s0);
-        t[0] = ta.x, t[1] = ta.y, t[2] = ta.z, t[3] = ta.w, t[4] = tb.x, t[5] = tb.y, t[6] = tb.z, t[7] = tb.w;
 #pragma unroll
-        for (uint32_t q = 0; q < SEG_PER; ++q) hf[q] = ((hb >> (8 * q)) & 1u) != 0;
+    for (uint32_t q4 = 0; q4 < SEG_PER; q4 += 4) { // (128-bit LDS reads)
+        const uint4 ta = *reinterpret_cast<const uint4 *>(st_idx + s0 + q4);
+        t[q4] = ta.x, t[q4 + 1] = ta.y, t[q4 + 2] = ta.z, t[q4 + 3] = ta.w;
     }
-    static_assert(SEG_PER == 8, "");
+#pragma unroll
+    for (uint32_t q8 = 0; q8 < SEG_PER; q8 += 8) {
+        const uint64_t hb = *reinterpret_cast<const uint64_t *>(st_head + s0 + q8);
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) hf[q8 + q] = ((hb >> (8 * q)) & 1u) != 0;
+    }
 #pragma unroll
     for (uint32_t q = 0; q < SEG_PER; ++q) {
         if (hf[q]) {
@@ -356,7 +369,7 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
         }
         k0[q] = k;
     }
-    sort8(k0); // (leaves a window without ties as it is: its keys ascend with the slot)
+    sort_own(k0); // (leaves a window without ties as it is: its keys ascend with the slot)
 #pragma unroll
     for (uint32_t q = 0; q < SEG_PER; ++q) key[seg_pos(s0 + q)] = k0[q];
     if (tie) any_tie = 1; // (every writer writes 1)
@@ -422,7 +435,7 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
     // the order and head flags on their way to lane-contiguous stores; the ranks scatter from here)
     uint32_t heads = 0;
     uint32_t tt[SEG_PER];
-    uint64_t flags8 = 0; // per slot: bit 0 = written by this workgroup, bit 1 = head
+    uint64_t flags8[SEG_PER / 8] = {}; // per slot one byte: bit 0 = written by this workgroup, bit 1 = head
 #pragma unroll
     for (uint32_t q = 0; q < SEG_PER; ++q) {
         const uint64_t k = kq[q];
@@ -432,12 +445,13 @@ __global__ __launch_bounds__(SEG_T, 8) void sa_segsort_kernel(const uint32_t *id
         const int g = ngh[q] >= 0 ? ngh[q] : nbefore; // >= F: the entry's own group begins with a head
         tt[q] = idx_in[base + (uint32_t)(k & 0x1FFFu)]; // (re-read through L2: 32 KiB of LDS less = two workgroups per CU)
         rank_new[tt[q]] = base + (uint32_t)g + 1u;
-        flags8 |= (uint64_t)(nh[q] ? 3u : 1u) << (8 * q);
+        flags8[q / 8] |= (uint64_t)(nh[q] ? 3u : 1u) << (8 * (q % 8));
         heads += nh[q] ? 1u : 0u;
     }
-    *reinterpret_cast<uint4 *>(st_idx + s0) = make_uint4(tt[0], tt[1], tt[2], tt[3]);
-    *reinterpret_cast<uint4 *>(st_idx + s0 + 4) = make_uint4(tt[4], tt[5], tt[6], tt[7]);
-    *reinterpret_cast<uint64_t *>(st_head + s0) = flags8;
+#pragma unroll
+    for (uint32_t q4 = 0; q4 < SEG_PER; q4 += 4) *reinterpret_cast<uint4 *>(st_idx + s0 + q4) = make_uint4(tt[q4], tt[q4 + 1], tt[q4 + 2], tt[q4 + 3]);
+#pragma unroll
+    for (uint32_t q8 = 0; q8 < SEG_PER; q8 += 8) *reinterpret_cast<uint64_t *>(st_head + s0 + q8) = flags8[q8 / 8];
     if (heads != 0) atomicAdd(&n_heads, heads);
     __syncthreads();
 #pragma unroll
