@@ -136,18 +136,24 @@ SLOT = 8192             # offsets per rank in the fixed-size all-gather slot (64
 
 
 def load_traffic(workload: str):
-    """HBM bytes per scan launch from the committed PMC pass (profiles/), or None."""
+    """(HBM bytes per scan launch, where the figure comes from): the committed PMC passes of profiles/ (FETCH_SIZE and
+    WRITE_SIZE need rocprofv3 runs of their own and cannot be read inside this process), or (None, None)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            d = json.load(f)
-        return d.get(workload, {}).get("hbm_bytes_per_launch")
+            d = json.load(f).get(workload, {})
+        if "hbm_bytes_per_launch" not in d:
+            return None, None
+        return d["hbm_bytes_per_launch"], (f"profiles/traffic.json <- profiles/{d.get('source', '?')} ({d.get('round', '?')}, builder's "
+                                           "rocprofv3 --pmc passes of this command; not measured in this run)")
     except (OSError, ValueError):
-        return None
+        return None, None
 
 
-def cpu_baseline(h_text: np.ndarray, pat: bytes, gpu_list: np.ndarray, budget_s: float):
-    """Serial CPU Boyer-Moore over the same text on this host (1 thread)."""
+def cpu_baseline(h_text: np.ndarray, pat: bytes, gpu_list: np.ndarray, budget_s: float, n_own=None, note=""):
+    """Serial CPU Boyer-Moore over the same text on this host (1 thread).  `n_own`: the text is a shard with a halo --
+    only the matches that START among its first n_own bytes are the shard's (shard.py's ownership rule); `gpu_list`
+    holds shard-local offsets then."""
     import oracle  # checker + reported baseline only; never on the product path
 
     chk = oracle.reference()
@@ -159,7 +165,7 @@ def cpu_baseline(h_text: np.ndarray, pat: bytes, gpu_list: np.ndarray, budget_s:
 
     tptr = C.c_void_p(h_text.ctypes.data)
     i32p, u64p = C.POINTER(C.c_int32), C.POINTER(C.c_uint64)
-    cap = max(1 << 16, gpu_list.size + 16)
+    cap = max(1 << 16, gpu_list.size + 4096)
     out = np.empty(cap, dtype=np.uint64)
     rates, passes, t_total, ok = [], 0, 0.0, None
     while passes < 1 or (t_total < budget_s and passes < 5):
@@ -171,11 +177,12 @@ def cpu_baseline(h_text: np.ndarray, pat: bytes, gpu_list: np.ndarray, budget_s:
         passes += 1
         rates.append(h_text.size / dt / 1e9)
         if ok is None:
-            ok = bool(found == gpu_list.size and np.array_equal(out[:found], gpu_list))
+            mine = out[:found] if n_own is None else out[:found][out[:found] < np.uint64(n_own)]
+            ok = bool(found <= cap and mine.size == gpu_list.size and np.array_equal(mine, gpu_list))
     return {
         "value": round(float(np.median(rates)), 3), "unit": "GB/s", "cores": 1, "kind": kind,
         "sample": f"whole {h_text.size} B text, {passes} serial pass(es), {t_total:.1f} s CPU, "
-                  f"{os.cpu_count()} host cores present",
+                  f"{os.cpu_count()} host cores present" + note,
     }, ok
 
 
@@ -397,9 +404,17 @@ def main():
     # first ~10 launches after the idle time of the set-up run 5-10 % slower (0.71, 0.72, 0.71, 0.70, 0.69, 0.68, 0.67,
     # 0.65 ms ... on config 2), which with --steps 20 --warmup 5 would be a fifth of the timed region.  --ramp-up 0 turns
     # it off; the line reports it (config.ramp_up_searches).
-    for i in range(max(len(lanes), args.ramp_up)):
+    n_ramp = max(len(lanes), args.ramp_up)
+    for i in range(n_ramp):
         step(i)
     fence()
+    # what the device's clocks do after the idle time of the set-up: the scan kernel's duration in the first launches
+    # of this process, oldest first, from the contexts' event rings (nothing is timed yet)
+    first_ms = []
+    hist = [lane["ctx"].scan_ms_history(min(lane["started"], 64))[::-1] for lane in lanes]  # oldest first, per lane
+    for j in range(max(len(h) for h in hist)):
+        first_ms += [h[j] for h in hist if j < len(h)]
+    first_ms = [round(float(x), 4) for x in first_ms[:5]]
     for i in range(args.warmup):
         step(i)
     fence()
@@ -433,6 +448,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         avg_scan_ms = float(t.item())
     achieved = n_own / (avg_scan_ms * 1e-3) / 1e9  # algorithmic bytes per launch: 1 B per owned text byte
+    traffic, traffic_source = load_traffic(args.workload)
     geom = ctx.geometry(m)
 
     # Not `value`, reported beside it: the same stream of searches with the scans of consecutive searches allowed to share
@@ -458,6 +474,8 @@ def main():
     line = {
         "metric": "GB/s of text scanned, 16-B pattern over 4 GiB ASCII, at 1/2/4/8 MI355X",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        # untimed searches in front of the timed region, all of them: --warmup plus the clock ramp-up (config.ramp_up_searches)
+        "warmup_effective": args.warmup + n_ramp,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "ranks_seen": dist.get_world_size() if multi else 1,
@@ -465,20 +483,39 @@ def main():
                   ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process"),
         "config": {"workload": spec.name, "text_bytes_total": spec.n, "text_bytes_per_gpu": n_own,
                    "pattern_bytes": m, "alphabet": "printable-95" if spec.kind == 0 else "ACGT",
-                   "matches": int(result.size), "searches_in_flight": len(lanes), "scans_overlap": bool(args.overlap_scans), "ramp_up_searches": max(len(lanes), args.ramp_up),
+                   "matches": int(result.size), "searches_in_flight": len(lanes), "scans_overlap": bool(args.overlap_scans), "ramp_up_searches": n_ramp,
+                   "kernel_ms_first_launches": first_ms,
                    "whole_job_GBps_if_scans_may_overlap": None if overlap_value is None else round(overlap_value, 1), "sharding": f"{world} contiguous shard(s) + {m - 1} B halo",
                    "exchange": ("REHEARSAL on one GPU, gloo via host" if rehearse else
                                 "RCCL all-gather of [count|offsets] slots") if multi else "none",
                    "kernel": f"{geom['kind']} block {geom['block']} seg {geom['seg']} grid {geom['grid']} "
                              f"lds {geom['lds_bytes']}"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic(args.workload),
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_ms": round(avg_scan_ms, 4), "algorithmic_bytes_per_launch": n_own},
         "parity": {"planted_offsets_exact": planted_ok},
     }
     if args.overlap_scans:  # launches share the GPU: one launch's duration is not the kernel's
         line["roofline"]["note"] = "scans overlap: kernel_ms is the span of a launch that shares the GPU with its neighbours; not comparable"
 
+    if world > 1 and not args.no_cpu_baseline:
+        # Every rank checks ITS shard of the merged global list against the reference's serial CPU scan of the shard's
+        # own bytes (copied to the host once, here, outside the timed region; one pass of one core per rank, the ranks
+        # side by side): the slice [start, start + n_own) of the list every rank ends a step with must be exactly what
+        # the CPU finds starting in the shard.  The AND over the ranks goes into the line.
+        h_shard = d_text.cpu().numpy()
+        lo = np.searchsorted(result, np.uint64(start), side="left")
+        hi = np.searchsorted(result, np.uint64(start + n_own), side="left")
+        mine = result[lo:hi] - np.uint64(start)
+        cb, exact = cpu_baseline(h_shard, pat, mine, 0.0, n_own=n_own,
+                                 note=f"; rank 0's shard, while the other {world - 1} rank(s) scan theirs on the same host")
+        del h_shard
+        agree = all(bool(np.array_equal(r, result)) for r in results)  # (both lanes hold the same global list)
+        flag = torch.tensor([1 if (exact and agree) else 0], dtype=torch.int64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        line["parity"]["bit_exact_vs_cpu_baseline_every_shard"] = bool(int(flag.item()) == 1)
+        line["parity"]["shards_checked"] = world
+        line["cpu_baseline"] = cb
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         h_text = d_text.cpu().numpy()
         cb, exact = cpu_baseline(h_text, pat, result, args.cpu_budget_s)

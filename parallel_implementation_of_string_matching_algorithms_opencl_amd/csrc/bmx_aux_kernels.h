@@ -147,37 +147,6 @@ __global__ __launch_bounds__(ORDER_THREADS) void order_kernel(uint64_t *out, uin
 
 // Exclusive scan of the per-tile match counts (dense results): tile_base[t] = matches in tiles before t.  One
 // workgroup; a 4 GiB text has 55 k tiles of 76 KiB = 54 rounds.
-// How many distinct byte values does the text use?  Four 4 KiB samples (start, thirds, end), a 256-bit set in LDS, the
-// count into pinned host memory.  The walker for a pattern depends on the TEXT's alphabet (a nine-letter English word
-// with eight distinct letters looks like a small-alphabet pattern and is not): bmx_shim.hip looks once per text.
-__global__ __launch_bounds__(256) void alphabet_sample_kernel(const uint8_t *text, uint64_t n, uint64_t *host_out, uint64_t seq)
-{
-    __shared__ uint32_t seen[8];
-    if (threadIdx.x < 8) seen[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t len = n < 4096 ? n : 4096;
-    uint32_t mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t c = 0; c < 4; ++c) {
-        const uint64_t at = (n - len) / 3 * c;
-        for (uint64_t i = threadIdx.x; i < len; i += 256) {
-            const uint32_t b = text[at + i];
-#pragma unroll
-            for (uint32_t w = 0; w < 8; ++w) mine[w] |= (b >> 5) == w ? 1u << (b & 31u) : 0u;
-        }
-    }
-#pragma unroll
-    for (uint32_t w = 0; w < 8; ++w)
-        if (mine[w] != 0) atomicOr(&seen[w], mine[w]);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t sigma = 0;
-        for (uint32_t w = 0; w < 8; ++w) sigma += (uint32_t)__popc(seen[w]);
-        host_out[0] = sigma;
-        __threadfence_system();
-        host_out[1] = seq;
-    }
-}
-
 __global__ __launch_bounds__(ORDER_THREADS) void tile_scan_kernel(const uint32_t *tile_count, uint64_t n_tiles, uint64_t *tile_base)
 {
     __shared__ uint64_t wave_total[ORDER_THREADS / 64];

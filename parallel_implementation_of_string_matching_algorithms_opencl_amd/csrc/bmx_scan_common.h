@@ -54,7 +54,8 @@ struct ScanArgs {
     // every tile's matches in ascending order at tile_base[tile]: no atomics, no sort, whatever the density.
     uint32_t *tile_count;      // fill pass only
     const uint64_t *tile_base; // fill pass only
-    uint32_t dense_enabled;    // 0: a full parking buffer sends the rest of its tile the direct way (global atomics)
+    uint32_t dense_enabled;    // bit 0 clear: a full parking buffer sends the rest of its tile the direct way (global atomics);
+                               // bit 1: short patterns, matches expected to be rare (ShortTile::mask looks for any match first)
     uint32_t bucket_shift;
     // Several patterns in one pass (bmx_search_device_multi; K == 0: the ordinary search).  `multi` is a blob of
     // multi_bytes bytes, per pattern [bad: 256 x u16 | good: m x u16, padded to 16 B | pattern, padded to 16 B] at
@@ -548,14 +549,17 @@ struct ShortTile {
     uint32_t first;     // tile-local position of this lane's chunk in round 0
     uint32_t m, p0, p1, p2, lo_w, hi_w;
     uint32_t ref; // the pattern as a little-endian word, 0 in the bytes behind it; 0 if a pattern byte is 0 (see mask())
+    bool sparse;  // wave-uniform: matches are expected to be rare -- look for ANY zero sum first (mask())
 
-    __device__ __forceinline__ void setup(const LdsTables &tb, uint32_t lo_t, uint32_t hi_t, uint32_t wave, uint32_t lane)
+    __device__ __forceinline__ void setup(const LdsTables &tb, uint32_t lo_t, uint32_t hi_t, uint32_t wave, uint32_t lane, bool sparse_)
     {
-        m = tb.m; // 1..3, wave-uniform
+        m = tb.m; // 1..4, wave-uniform (4: only without a zero byte -- the host sends other patterns to the walkers)
+        sparse = sparse_;
         p0 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[0]) * 0x01010101u;
         p1 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 1 ? 1 : 0]) * 0x01010101u;
         p2 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 2 ? 2 : 0]) * 0x01010101u;
-        ref = (p0 & 0xffu) | (m > 1 ? p1 & 0xff00u : 0u) | (m > 2 ? p2 & 0xff0000u : 0u);
+        const uint32_t p3 = __builtin_amdgcn_readfirstlane((uint32_t)tb.pat[m > 3 ? 3 : 0]);
+        ref = (p0 & 0xffu) | (m > 1 ? p1 & 0xff00u : 0u) | (m > 2 ? p2 & 0xff0000u : 0u) | (m > 3 ? p3 << 24 : 0u);
         if ((p0 & 0xffu) == 0 || (m > 1 && (p1 & 0xffu) == 0) || (m > 2 && (p2 & 0xffu) == 0)) ref = 0;
         // window starts of this wave's piece that are to be reported: [lo_w, hi_w)
         lo_w = lo_t > wave * PIECE ? lo_t : wave * PIECE;
@@ -591,14 +595,26 @@ struct ShortTile {
             // add with carry each; written out, hipcc selects constants with a wait state per compare: 48 slots for 32)
             x = 0;
             auto push = [&](uint32_t sum) { asm("v_cmp_eq_u32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : "v"(sum) : "vcc"); };
+            auto pack = [&]() {
 #pragma unroll
-            for (int j = 3; j >= 0; --j) push(r3[j]);
+                for (int j = 3; j >= 0; --j) push(r3[j]);
 #pragma unroll
-            for (int j = 3; j >= 0; --j) push(r2[j]);
+                for (int j = 3; j >= 0; --j) push(r2[j]);
 #pragma unroll
-            for (int j = 3; j >= 0; --j) push(r1[j]);
+                for (int j = 3; j >= 0; --j) push(r1[j]);
 #pragma unroll
-            for (int j = 3; j >= 0; --j) push(r0[j]);
+                for (int j = 3; j >= 0; --j) push(r0[j]);
+            };
+            if (sparse) { // (wave-uniform) a large alphabet: a chunk with a match is the exception (printable text, m = 2: one in
+                // 564; m = 3: one in 54,000) -- the smallest of the sixteen sums first, eight v_min3_u32 instead of
+                // the thirty-two instructions above, which only the lanes that hold a match then run
+                auto min3 = [](uint32_t u, uint32_t v, uint32_t w) { uint32_t r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(u), "v"(v), "v"(w)); return r; };
+                const uint32_t a0 = min3(r0.x, r0.y, r0.z), a1 = min3(r0.w, r1.x, r1.y), a2 = min3(r1.z, r1.w, r2.x), a3 = min3(r2.y, r2.z, r2.w);
+                const uint32_t a4 = min3(r3.x, r3.y, r3.z), b0 = min3(a0, a1, a2), b1 = min3(a3, a4, r3.w);
+                if ((b0 < b1 ? b0 : b1) == 0) pack();
+            } else {
+                pack();
+            }
         } else { // a pattern byte of 0 would be left out of the sums: the zero-byte masks
             x = mask_of(v.x, v.y) | (mask_of(v.y, v.z) << 4) | (mask_of(v.z, v.w) << 8) | (mask_of(v.w, nx) << 12);
         }
@@ -611,9 +627,9 @@ struct ShortTile {
 
     // this lane's matches among the window starts [lo_t, hi_t) of the tile; the masks stay in e[]
     __device__ __forceinline__ uint32_t count(const LdsTables &tb, const uint8_t *T, uint32_t lo_t, uint32_t hi_t, uint32_t wave,
-                                              uint32_t lane)
+                                              uint32_t lane, bool sparse_ = false)
     {
-        setup(tb, lo_t, hi_t, wave, lane);
+        setup(tb, lo_t, hi_t, wave, lane, sparse_);
         uint32_t cnt = 0;
 #pragma unroll
         for (uint32_t r = 0; r < ROUNDS; ++r) {
@@ -630,27 +646,26 @@ struct ShortTile {
 // A wave whose matches no longer fit leaves them out: the tile is dense, the workgroup finds out when it collects
 // the count and the fill pass writes the list.  (Without a fill pass -- experiment builds -- what does not fit goes
 // the direct way, as in report_hit.)  `count_only`: the workgroup has met a dense tile already.
+// Returns the wave's match count in this tile (wave-uniform): the caller stores it one tile period later (scan_body).
 template <uint32_t BLOCK, uint32_t TILE>
-__device__ __forceinline__ void park_tile_short(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo_t,
-                                                uint32_t hi_t, uint64_t tile_off, uint32_t wave, uint32_t lane, bool count_only,
-                                                uint32_t *wave_count /* this tile's BLOCK / 64 words, or null */)
+__device__ __forceinline__ uint32_t park_tile_short(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo_t,
+                                                    uint32_t hi_t, uint64_t tile_off, uint32_t wave, uint32_t lane, bool count_only)
 {
     ShortTile<BLOCK, TILE> st;
-    const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane);
+    const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane, (a.dense_enabled & 2u) != 0);
     const uint32_t incl = wave_inclusive_scan(cnt);
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-    if (wave_count != nullptr && lane == 0) wave_count[wave] = total; // the fill pass starts from these (dense results)
-    if (total == 0) return; // (wave-uniform)
+    if (total == 0) return 0; // (wave-uniform)
     const uint32_t addr = (uint32_t)(uintptr_t)tb.stage_cnt;
     if (count_only) {
         if (lane == 0) asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(total) : "memory");
-        return;
+        return total;
     }
     uint32_t base = 0;
     if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(addr), "v"(total) : "memory");
     base = __builtin_amdgcn_readfirstlane(base) - tb.stage_seen; // matches of this tile counted before this wave's
     const bool fits = base + total <= tb.stage_cap;
-    if (!fits && a.dense_enabled != 0) return;
+    if (!fits && a.dense_enabled != 0) return total;
     uint32_t idx = base + (incl - cnt);
 #pragma unroll
     for (uint32_t r = 0; r < ShortTile<BLOCK, TILE>::ROUNDS; ++r) {
@@ -668,6 +683,7 @@ __device__ __forceinline__ void park_tile_short(const ScanArgs &a, const LdsTabl
             x &= x - 1;
         }
     }
+    return total;
 }
 
 // The writing half.  A round's matches (up to 1024 of one wave) go to consecutive output slots; a lane holds those
@@ -687,7 +703,7 @@ __device__ __forceinline__ void fill_tile_short(const ScanArgs &a, const LdsTabl
     if (__builtin_amdgcn_readlane(wc, wave) == 0) return; // (wave-uniform)
     uint64_t at = tile_out + before;
     ShortTile<BLOCK, TILE> st;
-    st.setup(tb, lo_t, hi_t, wave, lane);
+    st.setup(tb, lo_t, hi_t, wave, lane, false);
     constexpr uint32_t BATCH = TILE <= 68u * 1024u ? 512u : 128u; // (what fits beside two tiles: bmx_shim.hip sizes the launch by it)
     static_assert(BLOCK == 1024, "sixteen waves share the area");
     const uint32_t area = (uint32_t)(uintptr_t)tb.fill_area + wave * (BATCH * 2u); // this wave's two-byte slots (LDS byte address)
@@ -891,8 +907,9 @@ __device__ __forceinline__ void walk_lane_sad(const ScanArgs &a, const LdsTables
                                               uint32_t lo_t, uint32_t hi_t, uint64_t tile_off)
 {
     constexpr uint32_t F = F8 ? 8 : 4;
-    const uint32_t m = tb.m;               // >= F
-    const uint32_t o = m - F;              // a window starting at p has its last F bytes at p + o
+    const uint32_t m = tb.m;               // >= F; or, F = 4 only, 1..3: the reference word is the whole pattern with zeros -- which
+                                           // the instruction leaves out of its sums -- behind it, and every stop is a match
+    const uint32_t o = m > F ? m - F : 0u; // a window starting at p has its last F bytes at p + o
     const uint32_t sbeg = (o & ~15u) + lane_idx * SAD_SEG; // this lane's first filter position: 16-byte aligned
     // filter positions that belong to a window to report: [lo_t + o, hi_t + o)
     if (sbeg >= hi_t + o || sbeg + SAD_SEG <= lo_t + o) return;
@@ -1046,6 +1063,9 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
     if (m >= 4)
         tb.sad_a = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 4] | ((uint32_t)a.tab.pat[m - 3] << 8) |
                                                   ((uint32_t)a.tab.pat[m - 2] << 16) | ((uint32_t)a.tab.pat[m - 1] << 24));
+    else // (walk_lane_sad on a pattern of 1-3 bytes: the pattern in the low bytes, nothing -- "any byte" -- above)
+        tb.sad_a = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[0] | (m > 1 ? (uint32_t)a.tab.pat[1] << 8 : 0u) |
+                                                  (m > 2 ? (uint32_t)a.tab.pat[2] << 16 : 0u));
     if (m >= 8)
         tb.sad_b = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 8] | ((uint32_t)a.tab.pat[m - 7] << 8) |
                                                   ((uint32_t)a.tab.pat[m - 6] << 16) | ((uint32_t)a.tab.pat[m - 5] << 24));

@@ -91,6 +91,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     static_assert(NL * 64 < BLOCK, "");
     static_assert(SEGI == 0 || (NL > 0 && SEGI % 4 == 0 && (SEGI / 4) % 2 == 1), "SEGI must be 4 * odd");
     constexpr uint32_t TILE = 64u * (uint32_t)(NL * SEGI + (NW - NL) * SEG);
+    // the scan proper (as opposed to the fill pass's two launches and the timing-only builds): the product (0), the
+    // product with a stolen tail (12), and the two with clock stamps (5, 8)
+    constexpr bool SCAN_MODE = MODE == 0 || MODE == 5 || MODE == 8 || MODE == 12;
     static_assert(TILE % 16 == 0, "tiles start on 16-B chunks");
 
     extern __shared__ uint4 smem_u4[];
@@ -221,6 +224,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         steal_begin = reserve >= 2 ? a.tile_begin + (per_wg - reserve) * gridDim.x : a.tile_end;
     }
     uint32_t it = 0; // tiles walked so far by this workgroup
+    uint32_t short_wc = 0; // WALK 6: matches this wave counted in the tile it walked last (wave-uniform)
     uint32_t seen[2] = {0, 0}; // the parking buffers' counts as of their last collection
     auto park_buf = [&](uint32_t p) { return tb.stage_area + p * tb.stage_cap; };
     auto park_cnt = [&](uint32_t p) { return tb.stage_area + 2 * tb.stage_cap + p; };
@@ -249,7 +253,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         //     finished walking the other buffer, which is refilled next.
         __builtin_amdgcn_s_waitcnt(0); // vmcnt(0) expcnt(0) lgkmcnt(0)
         if constexpr (ST)
-            if (ticket_pending && tid == 0) tb.wsum[31] = ticket; // (the request of the period before: back by now)
+            // (the request of the period before: back by now.  Two slots, alternating by period: the write sits in front of
+            // this period's barrier and the read right behind it, so the barrier orders them; the NEXT write -- one period
+            // on, again in front of a barrier but with no barrier between this period's read and it -- goes to the other slot)
+            if (ticket_pending && tid == 0) tb.wsum[30 + (it & 1u)] = ticket;
         if (MODE == 5) {
             const unsigned long long x = stamp();
             st_dma += x - st_prev;
@@ -267,7 +274,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             if (t + gridDim.x < steal_begin) { // the next tile of the static share
                 tn = t + gridDim.x;
             } else if (ticket_pending) { // a tile of the pool
-                const uint64_t k = steal_begin + tb.wsum[31];
+                const uint64_t k = steal_begin + tb.wsum[30 + (it & 1u)];
                 tn = k < a.tile_end ? k : NO_TILE;
                 pool_dry = tn == NO_TILE;
             } else {
@@ -292,6 +299,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             }
         }
         if (issue_now && !issue_late) issue_tile(tn, cur ? buf0 : buf1);
+        // Short patterns: what this wave counted in the PREVIOUS tile goes to HBM now (the fill pass of a dense result starts
+        // from these counts).  Stored right behind the walk -- as round 2 did -- the store is the youngest entry of vmcnt when
+        // the wave reaches the period's top, and the wait for the tile DMA there also waits for the store's acknowledgement:
+        // a write round trip on the critical path of every tile.  Issued here it has the whole walk to complete.
+        if constexpr (WALK == 6 && SCAN_MODE)
+            if (a.wave_count != nullptr && it != 0 && lane == 0)
+                a.wave_count[((ST ? t_prev : t - t_step) - a.tile_begin) * (uint64_t)NW + wave] = short_wc;
         // Matches parked while the PREVIOUS tile was walked: reserve their slots now (one global atomic by
         // one thread, not waited for; after the DMA issue, which must not wait for the LDS read here), park
         // this tile's matches in the other buffer meanwhile.
@@ -306,7 +320,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                 const uint32_t now = __builtin_amdgcn_readfirstlane(parked_now);
                 const uint32_t n_true = now - seen[pp]; // every match of that tile was counted, parked or not
                 seen[pp] = now;
-                if constexpr (WALK == 6 && MODE == 0) // m = 1..3: the fill pass (dense results) starts from these counts
+                if constexpr (WALK == 6 && SCAN_MODE) // m = 1..3: the fill pass (dense results) starts from these counts
                     if (a.tile_count != nullptr && tid == 0) a.tile_count[(ST ? t_prev : t - t_step) - a.tile_begin] = n_true;
                 if (dense_mode && (wg_dense || n_true > tb.stage_cap)) { // (wave-uniform: tb.sink is a per-lane state)
                     // a dense tile: nothing of it is stored -- the fill pass will write the whole list -- and from here
@@ -405,6 +419,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                 walk_tile();
             }
             const uint32_t c = wave_sum(tb.lane_cnt);
+            if constexpr (WALK == 6) // (the writing half starts every wave behind the counts of the tile's earlier waves)
+                if (a.wave_count != nullptr && lane == 0) a.wave_count[(t - a.tile_begin) * (uint64_t)NW + wave] = c;
             if (lane == 0) tb.wsum[wave] = c;
             __syncthreads(); // (the next tile's top barrier separates these reads from the next writes)
             if (tid == 0) {
@@ -437,11 +453,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             if (mine != 0) walk_tile(); // (per lane: a lane without matches has nothing to write)
             }
         } else {
-            if constexpr (WALK == 6 && MODE == 0 && LOADERS == 0 && GRADE == 0) {
+            if constexpr (WALK == 6 && SCAN_MODE && LOADERS == 0 && GRADE == 0) {
                 if (tb.stage_cap != 0) { // m = 1..3: sixteen window starts per 128-bit read, one LDS atomic per wave and tile
                     const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
-                    park_tile_short<BLOCK, TILE>(a, tb, T, lo_t, rem < (uint64_t)TILE ? (uint32_t)rem : TILE, tile_off, wave, lane, wg_dense,
-                                                 a.wave_count != nullptr ? a.wave_count + (t - a.tile_begin) * (uint64_t)NW : nullptr);
+                    short_wc = park_tile_short<BLOCK, TILE>(a, tb, T, lo_t, rem < (uint64_t)TILE ? (uint32_t)rem : TILE, tile_off, wave, lane, wg_dense);
                 } else {
                     walk_tile();
                 }
@@ -483,7 +498,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         __syncthreads();
         const uint32_t pp = (it & 1u) ^ 1u;
         const uint32_t n_true = __builtin_amdgcn_readfirstlane(*park_cnt(pp)) - seen[pp];
-        if constexpr (WALK == 6 && MODE == 0)
+        if constexpr (WALK == 6 && SCAN_MODE)
+            if (a.wave_count != nullptr && lane == 0) a.wave_count[((STEAL ? t_prev : t - t_step) - a.tile_begin) * (uint64_t)NW + wave] = short_wc;
+        if constexpr (WALK == 6 && SCAN_MODE)
             if (a.tile_count != nullptr && tid == 0) a.tile_count[(STEAL ? t_prev : t - t_step) - a.tile_begin] = n_true;
         if (dense_mode && (wg_dense || n_true > tb.stage_cap)) {
             dense_total += n_true;

@@ -26,6 +26,9 @@
 #include "bmx_ed_kernel.h"
 #include "bmx_scan_ring_kernel.h"
 #include "bmx_scan_wave_kernel.h"
+#ifdef BMX_EXPERIMENTS
+#include "bmx_probe_kernel.h"
+#endif
 
 static_assert(bmx::MAX_PATTERN == BMX_MAX_PATTERN, "header and kernel disagree");
 static_assert(bmx::MAX_MULTI == BMX_MAX_MULTI, "header and kernel disagree");
@@ -102,7 +105,7 @@ struct Variant {
 #define BMX_TILE_LS(B, S, AUX, MODE, W, L, SI) BMX_TILE_G(B, S, AUX, MODE, W, L, SI, 0)
 #define BMX_TILE_G(B, S, AUX, MODE, W, L, SI, G) \
     {0, B, S, 2, L, SI, (MODE) == 5 || (MODE) == 8, (W) == 3 || (W) == 10, \
-     (W) == 3 || (W) == 7 || (W) == 9 ? 4 : ((W) == 8 || (W) == 10 ? 8 : 0), \
+     (W) == 7 ? 1 : ((W) == 3 || (W) == 9 ? 4 : ((W) == 8 || (W) == 10 ? 8 : 0)), \
      bmx::scan_kernel<B, S, AUX, MODE, W, L, SI, G>, bmx::scan_kernel<B, S, AUX, MODE, 6, L, SI, G>, nullptr, nullptr, nullptr, nullptr}
 // a product geometry: with the fill pass for dense results (byte-wise walker / short-pattern walker on the same tiles)
 #define BMX_TILE_F(B, S, AUX, W) \
@@ -111,9 +114,15 @@ struct Variant {
      bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>}
 // ... and with static shares + a stolen tail (scan_kernel MODE 12); short patterns and the fill pass as in BMX_TILE_F
 #define BMX_TILE_S(B, S, AUX, W) \
-    {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 3 ? 4 : ((W) == 10 ? 8 : 0), bmx::scan_kernel<B, S, AUX, 12, W>, \
+    {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 7 ? 1 : ((W) == 3 ? 4 : ((W) == 10 || (W) == 8 ? 8 : 0)), bmx::scan_kernel<B, S, AUX, 12, W>, \
      bmx::scan_kernel<B, S, AUX, 0, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>, \
      bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>, true}
+// a product geometry with clock stamps (MODE 5: per tile phase, MODE 8: two stamps around the loop): everything the
+// product kernel does, the per-tile counts of short patterns included
+#define BMX_TILE_FM(B, S, AUX, MODE, W) \
+    {0, B, S, 2, 0, 0, true, (W) == 3 || (W) == 10, (W) == 3 ? 4 : ((W) == 10 ? 8 : 0), bmx::scan_kernel<B, S, AUX, MODE, W>, \
+     bmx::scan_kernel<B, S, AUX, MODE, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>, \
+     bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>}
 #define BMX_TILE_W32(B, S, AUX, MODE, W) /* 32 waves per CU: the 80-SGPR build */ \
     {0, B, S, 2, 0, 0, (MODE) == 5, (W) == 3, (W) == 3 ? 4 : 0, bmx::scan_kernel_w32<B, S, AUX, MODE, W, 0>, bmx::scan_kernel_w32<B, S, AUX, (MODE) == 12 ? 0 : (MODE), 6, 0>, \
      (MODE) == 0 || (MODE) == 12 ? bmx::scan_kernel<B, S, AUX, 9, 0> : nullptr, (MODE) == 0 || (MODE) == 12 ? bmx::scan_kernel<B, S, AUX, 9, 6> : nullptr, \
@@ -215,6 +224,12 @@ const Variant g_variants[] = {
     BMX_EXP(BMX_TILE_F(1024, 76, 2, 10)),              // 80: variant 53 without its stolen tail (static shares only)
     BMX_EXP(BMX_TILE_F(1024, 76, 2, 3)),               // 81: variant 54 (4-gram walker) without its stolen tail
     BMX_TILE_W32(1024, 36, 2, 12, 2),                  // 82: PRODUCT -- variant 2 (skip loop, two workgroups per CU) with a stolen tail: large alphabets, m = 9..12
+    BMX_EXP(BMX_TILE_FM(1024, 68, 2, 5, 0)),           // 83: variant 0 with stamps per tile phase, fill pass and per-tile counts as in the product (short patterns: m < 4)
+    BMX_EXP(BMX_TILE_FM(1024, 76, 2, 5, 0)),           // 84: variant 29 likewise
+    BMX_EXP(BMX_TILE_FM(1024, 68, 2, 8, 0)),           // 85: variant 0 with the two clock stamps only
+    BMX_EXP(BMX_TILE_FM(1024, 76, 2, 8, 0)),           // 86: variant 29 likewise
+    BMX_EXP(BMX_TILE_S(1024, 76, 2, 7)),               // 87: variant 30 (quad-SAD skip loop, last 4 bytes; m < 4: the whole pattern) with a stolen tail
+    BMX_EXP(BMX_TILE_S(1024, 76, 2, 8)),               // 88: variant 31 (last 8 bytes, m >= 8) with a stolen tail
 };
 constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
@@ -226,10 +241,11 @@ struct bmx_ctx {
     int num_cu = 256;
     int variant = 0;
     bool auto_walker = true; // until bmx_set_variant(): the walker by the pattern and the text's alphabet (pick_variant)
-    // distinct byte values of the texts seen last (alphabet_sample_kernel), by device pointer and length
-    struct { const void *ptr; uint64_t n; int sigma; } sampled[4] = {};
-    int sampled_next = 0;
-    uint64_t sample_seq = 0;
+    // distinct byte values of the texts seen last (sampled by order_kernel behind every search), by device pointer and length
+    static constexpr int N_SAMPLED = 16;
+    struct { const void *ptr; uint64_t n; int sigma; } sampled[N_SAMPLED] = {};
+    unsigned sampled_next = 0;
+    bool text_sample = true; // (libbmx_exp.so can switch it off: the walker then goes by the pattern's symbols)
     const void *last_text = nullptr; // the text of the search whose status is awaited (its order_kernel samples it again)
     uint64_t last_text_n = 0;
     int last_variant = 0;    // what the most recent search ran (bmx_scan_geometry reports it)
@@ -254,6 +270,8 @@ struct bmx_ctx {
     bmx::ScanArgs last_args;               // the last scan launch (the fill pass re-runs its geometry)
     int last_grid = 0;
     int32_t last_m = 0;
+    bool last_short = false;               // ... was for a short pattern (short_pattern(): its fill pass tests every position, nothing is walked)
+    bool last_counted = false;             // ... and its scan kernel left the per-tile / per-wave match counts the fill pass starts from
     bool last_fillable = false;
     uint32_t *d_bucket_cnt = nullptr;      // ORDER_BUCKETS, re-armed by order_kernel
     uint64_t *d_bucket_store = nullptr;    // ORDER_BUCKETS x ORDER_BUCKET_CAP
@@ -345,14 +363,23 @@ constexpr int VARIANT_BIG_TILE = 29; // 76 KiB tiles: +2 % on large alphabets, b
 // The q-gram rules pay on small alphabets only, and whether the alphabet is small is a property of the text: the
 // pattern's own distinct symbols (all there was to go by until round 2's second half) say "small" for every short
 // English word -- `Tennessee` ran the 8-gram walker at 2.6 TB/s on English text.
-int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical, int sigma)
+// Patterns that are not walked at all (ShortTile, bmx_scan_common.h): with m <= 4 the shift tables cannot skip anything worth
+// two dependent LDS reads per window, and one v_mqsad_u32_u8 tests four window starts against up to four pattern bytes
+// (a reference byte of 0 is left out of the sums: a pattern of four bytes with a zero byte goes to the walkers).
+bool short_pattern(const char *pat, int32_t m)
 {
-    if (!ctx->auto_walker) { // an explicitly chosen variant
-        const Variant &v = g_variants[ctx->variant];
-        if (v.canon_minm && (!canonical || m < v.canon_minm)) return m >= 4 ? 2 : 0;
-        return lds_bytes_for(v, m) <= LDS_PER_CU ? ctx->variant : 0; // buffers + halo do not fit at this m -> default
-    }
-    if (m < 4) return 0;
+    if (m <= 3) return true;
+    return m == 4 && pat[0] != 0 && pat[1] != 0 && pat[2] != 0 && pat[3] != 0;
+}
+
+// *sparse (short patterns only): matches are expected to be rare -- fewer than 64 per 76 KiB tile on a text that is uniform
+// over `sigma` symbols -- so the kernel takes 76 KiB tiles (room for 512 parked matches) and looks for ANY match in a
+// chunk before it works out which (ShortTile::mask).  A text that is not uniform (English: `is` is in one position of
+// 150) only costs this choice what a dense result costs anyway: its tiles are counted and the fill pass writes the list.
+int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical, int sigma, bool *sparse, bool *use_short_kernel)
+{
+    *sparse = false;
+    *use_short_kernel = short_pattern(pat, m);
     bool seen[256] = {};
     int distinct = 0;
     for (int i = 0; i < m; ++i)
@@ -361,6 +388,19 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
             ++distinct;
         }
     auto fits = [&](int vi) { return lds_bytes_for(g_variants[vi], m) <= LDS_PER_CU; };
+    const bool is_short = short_pattern(pat, m);
+    if (is_short) {
+        double per_tile = 77824.0;
+        for (int i = 0; i < m; ++i) per_tile /= (double)(sigma > 0 ? sigma : distinct);
+        *sparse = per_tile < 64.0;
+    }
+    if (!ctx->auto_walker) { // an explicitly chosen variant
+        const Variant &v = g_variants[ctx->variant];
+        if (v.canon_minm && (!canonical || m < v.canon_minm)) return !is_short ? 2 : 0;
+        if (v.canon_minm == 1) *use_short_kernel = false; // the quad-SAD skip loop takes any m
+        return lds_bytes_for(v, m) <= LDS_PER_CU ? ctx->variant : 0; // buffers + halo do not fit at this m -> default
+    }
+    if (is_short) return *sparse && fits(VARIANT_BIG_TILE) ? VARIANT_BIG_TILE : 0;
     const bool large_alphabet = sigma > 0 ? sigma > 8 : distinct > 8;
     if (large_alphabet) { // sparse by nature (9^-4 and less)
         // short patterns: long walks, 32 waves per CU hide them better (4 GiB printable text, ms, byte-wise 76 KiB / skip loop
@@ -383,23 +423,29 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
     return 2;
 }
 
-// Distinct byte values of the text at d_text (four 4 KiB samples), remembered per (pointer, length): one tiny kernel
-// and one wait of ~20 us when a text is seen for the first time.  0 if it cannot be had.
-int text_sigma(bmx_ctx *ctx, const void *d_text, uint64_t n, hipStream_t stream)
+// Distinct byte values of the text at (d_text, n), as far as this context knows them: the ordering kernel of EVERY search
+// samples 4 x 256 bytes of the text it has just scanned (free: four loads per thread of four waves) and
+// bmx_search_device_finish files the count here.  0 = not seen yet: the first search on a text goes by the pattern's own
+// symbols and is corrected one search later -- an enqueue never waits for the device (round 2 sampled a new text on the
+// spot: one kernel and one stream synchronisation inside bmx_search_device_enqueue).
+int text_sigma(const bmx_ctx *ctx, const void *d_text, uint64_t n)
 {
-    if (n == 0 || getenv("BMX_NO_TEXT_SAMPLE")) return 0;
-    for (auto &e : ctx->sampled)
+    if (n == 0 || !ctx->text_sample) return 0;
+    for (const auto &e : ctx->sampled)
         if (e.ptr == d_text && e.n == n) return e.sigma;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0; // (no wait inside a graph capture)
-    const uint64_t seq = ++ctx->sample_seq;
-    hipLaunchKernelGGL(bmx::alphabet_sample_kernel, dim3(1), dim3(256), 0, stream, (const uint8_t *)d_text, n, ctx->h_status_dev + 4, seq);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return 0;
-    if (__atomic_load_n(&ctx->h_status[5], __ATOMIC_ACQUIRE) != seq) return 0;
-    const int sigma = (int)ctx->h_status[4];
-    auto &slot = ctx->sampled[ctx->sampled_next++ & 3];
+    return 0;
+}
+
+void remember_sigma(bmx_ctx *ctx, const void *d_text, uint64_t n, int sigma)
+{
+    if (sigma <= 0 || d_text == nullptr) return;
+    for (auto &e : ctx->sampled)
+        if (e.ptr == d_text && e.n == n) {
+            e.sigma = sigma; // the text as it is NOW (a caller may put another text at the same address: one search late, not wrong for ever)
+            return;
+        }
+    auto &slot = ctx->sampled[ctx->sampled_next++ % bmx_ctx::N_SAMPLED];
     slot.ptr = d_text, slot.n = n, slot.sigma = sigma;
-    return sigma;
 }
 
 // Convert the caller's int32 tables (or build them) into the kernel-argument layout.
@@ -602,7 +648,8 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
             ctx->armed = true; // nothing was launched
             return rc;
         }
-        const int vi = pick_variant(ctx, pat, m, canonical, ctx->auto_walker && m >= 4 ? text_sigma(ctx, d_text, n, stream) : 0);
+        bool sparse = false, is_short = false; // is_short: the launch is the short-pattern kernel (ShortTile), which leaves per-tile counts
+        const int vi = pick_variant(ctx, pat, m, canonical, text_sigma(ctx, d_text, n), &sparse, &is_short);
         ctx->last_variant = vi;
         const Variant &v = g_variants[vi];
         const uint64_t tile = unit_bytes(v);
@@ -641,8 +688,8 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
             ctx->armed = true;
             return BMX_ERR_ARG;
         }
-        auto kernel = m >= 4 ? v.kernel : v.kernel_short;
-        int &attr = m >= 4 ? ctx->lds_attr_set[vi] : ctx->lds_attr_set_short[vi];
+        auto kernel = !is_short ? v.kernel : v.kernel_short;
+        int &attr = !is_short ? ctx->lds_attr_set[vi] : ctx->lds_attr_set_short[vi];
         if (attr < (int)lds) {
             HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = (int)lds;
@@ -655,10 +702,10 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
             grid = std::min<uint32_t>(grid, (uint32_t)std::max(1, atoi(g)));
 
         // dense results: the scan counts per tile, bmx_search_device_finish runs the fill pass of this geometry
-        auto fill = m >= 4 ? v.fill : v.fill_short;
+        auto fill = !short_pattern(pat, m) ? v.fill : v.fill_short;
         if (getenv("BMX_NO_DENSE")) fill = nullptr; // (tools/: A/B runs)
         ctx->last_fillable = false;
-        if (fill != nullptr && a.stage_cap != 0) a.dense_enabled = 1; // (count-only calls too: dense tiles are just counted)
+        if (fill != nullptr && a.stage_cap != 0) a.dense_enabled = 1u | (is_short && sparse ? 2u : 0u); // (count-only calls too: dense tiles are just counted)
         if (fill != nullptr && a.stage_cap != 0 && out != nullptr) {
             const uint64_t n_tiles = a.tile_end - a.tile_begin;
             if (ctx->tile_cap < n_tiles) {
@@ -672,7 +719,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
                 ctx->tile_cap = n_tiles;
             }
             ctx->last_fillable = true;
-            if (m < 4) a.tile_count = ctx->d_tile_count, a.wave_count = ctx->d_wave_count; // the short-pattern scan leaves the counts itself
+            if (is_short) a.tile_count = ctx->d_tile_count, a.wave_count = ctx->d_wave_count; // the short-pattern scan leaves the counts itself
         }
         const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
         if (v.stamps) { // diagnostic build: room for 8 words per wave
@@ -689,12 +736,14 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(v.block), lds, stream, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
-        if (v.steal && m >= 4) expect_tiles = (uint32_t)(a.tile_end - a.tile_begin);
+        if (v.steal && !is_short) expect_tiles = (uint32_t)(a.tile_end - a.tile_begin);
         ctx->n_timed++;
         ctx->timed = true;
         ctx->last_args = a;
         ctx->last_grid = (int)grid;
         ctx->last_m = m;
+        ctx->last_short = short_pattern(pat, m); // (the fill pass of a short pattern is ShortTile's, whatever kernel scanned)
+        ctx->last_counted = is_short;
     } else {
         ctx->last_fillable = false;
     }
@@ -702,7 +751,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     // ascending list from the position buckets, {count, needs_sort} for the host, counters re-armed
     hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, out, capacity, ctx->d_count,
                        ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status, ctx->h_status_dev,
-                       ++ctx->seq, (uint64_t *)nullptr, 1u, ctx->auto_walker && !getenv("BMX_NO_TEXT_SAMPLE") ? (const uint8_t *)d_text : nullptr, n,
+                       ++ctx->seq, (uint64_t *)nullptr, 1u, ctx->text_sample ? (const uint8_t *)d_text : nullptr, n,
                        expect_tiles);
     ctx->last_text = d_text, ctx->last_text_n = n;
     HIPCHK(hipGetLastError());
@@ -741,9 +790,7 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
     }
     const uint64_t total = ctx->h_status[0];
     const bool needs_sort = ctx->h_status[1] == 1;
-    if (ctx->h_status[6] != 0) // the text as it is NOW (a caller may put another text at the same address: one search late, not wrong for ever)
-        for (auto &e : ctx->sampled)
-            if (e.ptr == ctx->last_text && e.n == ctx->last_text_n) e.sigma = (int)ctx->h_status[6];
+    remember_sigma(ctx, ctx->last_text, ctx->last_text_n, (int)ctx->h_status[6]);
     if (ctx->h_status[3] != 0) { // finish_parked (bmx_scan_common.h): matches were dropped, the list is not the answer
         if (ctx->h_status[3] & 2)
             set_err("scan kernel: the workgroups did not walk every tile exactly once between them (stolen tail); result discarded");
@@ -760,7 +807,7 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
     // 65 ns per thousand matches (16.8 M matches: 1.1 ms).
     // (Only for patterns of 1-3 bytes, whose fill pass tests every position from registers: the byte-wise walker
     // of the longer ones, run twice over a small alphabet, is slower than the sort -- 1 GiB ACGT, m = 4: 3.3 vs 1.9 ms.)
-    const bool fill_instead_of_sort = needs_sort && ctx->last_fillable && ctx->last_m < 4 && d_match_positions && capacity > 0 &&
+    const bool fill_instead_of_sort = needs_sort && ctx->last_fillable && ctx->last_short && d_match_positions && capacity > 0 &&
                                       (double)(ctx->last_args.data_end) / 4.0e9 < 0.1 + (double)stored * 6.5e-8;
     if ((ctx->h_status[1] == 2 || fill_instead_of_sort) && d_match_positions && capacity > 0) {
         // Dense result: some tile held more matches than its workgroup can park in LDS.  The scan has counted every
@@ -772,10 +819,10 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
             return BMX_ERR_HIP;
         }
         const Variant &v = g_variants[ctx->last_variant];
-        auto fill = ctx->last_m >= 4 ? v.fill : v.fill_short;
+        auto fill = !ctx->last_short ? v.fill : v.fill_short;
         bmx::ScanArgs a = ctx->last_args;
         const uint64_t n_tiles = a.tile_end - a.tile_begin;
-        auto fill_count = ctx->last_m >= 4 ? v.fill_count : v.fill_count_short;
+        auto fill_count = !ctx->last_short ? v.fill_count : v.fill_count_short;
         a.out = d_match_positions;
         a.cap = capacity;
         a.stage_cap = 0;
@@ -783,9 +830,10 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
         a.tile_count = ctx->d_tile_count;
         a.dense_enabled = 0;
         // (m = 1..3: 1 KiB per wave in the parking area's place, where the fill pass lays a round's matches out in slot order)
-        const uint32_t lds = lds_bytes_with(v, ctx->last_m, ctx->last_m < 4 ? (v.seg > 68 ? 512u : 2048u) : 0u); // (ShortTile::BATCH x 4)
+        const uint32_t lds = lds_bytes_with(v, ctx->last_m, ctx->last_short ? (v.seg > 68 ? 512u : 2048u) : 0u); // (ShortTile::BATCH x 4)
         HIPCHK(hipFuncSetAttribute((const void *)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (ctx->last_m >= 4) { // (the scan of a short pattern has left the tile counts already)
+        if (!ctx->last_counted) { // (the short-pattern kernel has left the counts already)
+            a.wave_count = ctx->d_wave_count;
             HIPCHK(hipFuncSetAttribute((const void *)fill_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(fill_count, dim3(ctx->last_grid), dim3(v.block), lds, stream, a);
             HIPCHK(hipGetLastError());
@@ -915,7 +963,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     ctx->armed = false;
     if (getenv("BMX_MULTI_NO_QGRAM")) qmask = 0; // (tools/: A/B runs)
     if (qmask != 0) { // ... and only if the TEXT's alphabet is small (pick_variant)
-        const int sigma = text_sigma(ctx, d_text, n, stream);
+        const int sigma = text_sigma(ctx, d_text, n);
         if (sigma > 8) qmask = 0;
     }
     const uint32_t q_bytes = (uint32_t)__builtin_popcount(qmask) * bmx::QGRAM_TABLE;
@@ -1581,6 +1629,58 @@ int bmx_search_ranges(bmx_ctx *ctx_in, const char *text, uint64_t n, const char 
     if (!ctx_in) bmx_ctx_destroy(ctx);
     return rc;
 }
+
+#ifdef BMX_EXPERIMENTS
+// libbmx_exp.so only (tools/hbm_read_probe.py): read-only sweep of n bytes at d_text with plain global loads into
+// registers -- no LDS, no barrier, no tiles (bmx_probe_kernel.h).  `unroll` loads in flight per lane (4, 8, 16), `nt`
+// cache policy, `block` threads per workgroup, `blocks_per_cu` of them per CU.  ms_out[i] = duration of launch i (HIP
+// events on `stream`).
+int bmx_probe_read(bmx_ctx *ctx, const void *d_text, uint64_t n, int block, int blocks_per_cu, int unroll, int nt,
+                   int launches, float *ms_out, void *stream_v)
+{
+    if (!ctx || !d_text || !ms_out || launches < 1 || block < 64 || block > 1024 || block % 64 || blocks_per_cu < 1) return BMX_ERR_ARG;
+    if (((uintptr_t)d_text & 15u) != 0) return BMX_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_v;
+    HIPCHK(hipSetDevice(ctx->device));
+    void (*k)(const uint8_t *, uint64_t, uint32_t *) = nullptr;
+    switch (unroll * 2 + (nt ? 1 : 0)) {
+    case 2: k = bmx::probe_read_kernel<1, 0>; break;
+    case 3: k = bmx::probe_read_kernel<1, 1>; break;
+    case 4: k = bmx::probe_read_kernel<2, 0>; break;
+    case 5: k = bmx::probe_read_kernel<2, 1>; break;
+    case 8: k = bmx::probe_read_kernel<4, 0>; break;
+    case 9: k = bmx::probe_read_kernel<4, 1>; break;
+    case 16: k = bmx::probe_read_kernel<8, 0>; break;
+    case 17: k = bmx::probe_read_kernel<8, 1>; break;
+    case 32: k = bmx::probe_read_kernel<16, 0>; break;
+    case 33: k = bmx::probe_read_kernel<16, 1>; break;
+    default: return BMX_ERR_ARG;
+    }
+    uint32_t *d_sink = nullptr;
+    HIPCHK(hipMalloc(&d_sink, sizeof(uint32_t)));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    hipError_t e = hipMemsetAsync(d_sink, 0, sizeof(uint32_t), stream);
+    const uint32_t grid = (uint32_t)(ctx->num_cu * blocks_per_cu);
+    for (int i = 0; i < launches && e == hipSuccess; ++i) {
+        e = hipEventRecord(e0, stream);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(block), 0, stream, (const uint8_t *)d_text, n >> 4, d_sink);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(e1, stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms_out[i], e0, e1);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d_sink);
+    if (e != hipSuccess) {
+        set_err("bmx_probe_read: %s", hipGetErrorString(e));
+        return BMX_ERR_HIP;
+    }
+    return BMX_OK;
+}
+#endif
 
 int bmx_gen_text_device(bmx_ctx *ctx, void *d_dst, uint64_t start, uint64_t len, uint64_t seed, int kind,
                         void *stream_v)

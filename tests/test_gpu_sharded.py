@@ -113,7 +113,9 @@ def _run(world, spec_args, slot):
     return got
 
 
-@pytest.mark.parametrize("world", [2, 3])
+# (world 5 + this process = 6 processes on the card, the most a GPU box admits; the 8-rank world of BASELINE config 4
+# runs on gloo in tests/test_shard_gloo.py and, for the slot merge, in one process below)
+@pytest.mark.parametrize("world", [2, 3, 5])
 def test_sharded_scan_with_slot_exchange(world, port, ctx):
     from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus
 
@@ -124,6 +126,42 @@ def test_sharded_scan_with_slot_exchange(world, port, ctx):
     assert np.array_equal(want, spec.planted_offsets())
     got = _run(world, spec_args, slot=8192)
     assert np.array_equal(got, want)
+
+
+def test_eight_shard_slot_merge_in_one_process(port, ctx):
+    """BASELINE config 4's world of 8 without 8 processes on the card: one process scans the eight shards one after the
+    other with the HIP kernel (each with its halo, ownership and global offsets), lays their [count | offsets] slots out
+    as the all-gather would, and runs the 8-slot merge kernel.  The merged list must be the unsharded oracle's."""
+    import torch
+
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus, host, shard
+
+    world, slot = 8, 8192
+    n = 40 * (1 << 20) + 4321
+    per = shard.shard_bounds(n, world, 0)[1]
+    spec = corpus.CorpusSpec("merge8", n, 16, 0, 0x5EED0004, 1 << 17, per, -1)  # forced hits across every cut
+    h_text = spec.host_text()
+    want = port.search(h_text, spec.pattern())
+    for r in range(1, world):
+        cut = shard.shard_bounds(n, world, r)[0]
+        assert any(p < cut < p + 16 for p in want.tolist())
+    dev = torch.device("cuda", 0)
+    d_all = torch.from_numpy(h_text).to(dev)
+    gathered = torch.zeros(world * (slot + 1), dtype=torch.int64, device=dev)
+    tables = host.build_tables(spec.pattern())
+    for r in range(world):
+        start, length, n_own = shard.shard_extent(n, spec.m, world, r)
+        buf = gathered[r * (slot + 1):(r + 1) * (slot + 1)]
+        q = ctx.prepare(d_all[start:start + length], spec.pattern(), buf[1:], n=length, n_own=n_own, base_offset=start, tables=tables)
+        q.enqueue()
+        ctx.count_to_device(buf)
+        q.finish()
+    merged = torch.zeros(world * slot, dtype=torch.int64, device=dev)
+    totals = torch.zeros(3, dtype=torch.int64).pin_memory()
+    ctx.merge_gathered(gathered, world, slot + 1, merged, totals, 7)
+    torch.cuda.synchronize()
+    assert int(totals[2]) == 7 and int(totals[0]) == want.size
+    assert np.array_equal(merged[:want.size].cpu().numpy().astype(np.uint64), want)
 
 
 def test_sharded_scan_dense_result_takes_exact_exchange(port, ctx):
@@ -159,6 +197,8 @@ def test_bench_multi_rank_path_rehearsal(ctx):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["unit"] == "GB/s"
     assert line["ranks_seen"] == 2 and line["launch"] == "torch.distributed.run"
     assert line["parity"]["planted_offsets_exact"] is True
+    assert line["parity"]["bit_exact_vs_cpu_baseline_every_shard"] is True and line["parity"]["shards_checked"] == 2
+    assert line["cpu_baseline"]["cores"] == 1 and line["warmup_effective"] >= line["warmup"]
     assert line["config"]["text_bytes_total"] == 2 * line["config"]["text_bytes_per_gpu"]
     assert line["config"]["matches"] > 500 and line["roofline"]["bound"] == "hbm"
 
@@ -183,7 +223,16 @@ def test_bench_plain_launch_starts_its_own_ranks(ctx):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["launch"] == "self-launched ranks"
     assert line["parity"]["planted_offsets_exact"] is True
+    assert line["parity"]["bit_exact_vs_cpu_baseline_every_shard"] is True
     assert line["config"]["text_bytes_total"] == 2 * line["config"]["text_bytes_per_gpu"]
+    # four ranks (with this process: five on the card; a GPU box admits six), each checking its own shard on the CPU
+    r4 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1",
+                         "--gib-per-gpu", "0.0625", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=600,
+                        cwd=ROOT, env=env)
+    assert r4.returncode == 0, r4.stderr[-2000:]
+    l4 = json.loads([l for l in r4.stdout.splitlines() if l.startswith("{")][-1])
+    assert l4["n_gpus"] == 4 and l4["ranks_seen"] == 4 and l4["parity"]["shards_checked"] == 4
+    assert l4["parity"]["bit_exact_vs_cpu_baseline_every_shard"] is True and l4["parity"]["planted_offsets_exact"] is True
     # a rank that fails must fail the parent (and not hang it): an unknown workload makes argparse exit 2 in
     # the parent itself, a bad variant fails inside the ranks
     bad = subprocess.run(cmd + ["--variant", "12"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)

@@ -41,11 +41,12 @@ def _worker(rank, world, port, spec_args, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_search_equals_unsharded(world, port):
-    # boundary_period chosen so that forced hits straddle the shard boundaries
+    # boundary_period chosen so that forced hits straddle the shard boundaries (world 8 = BASELINE config 4's world:
+    # a forced hit sits across EVERY one of the seven cuts)
     n = 3 * (1 << 18)
-    spec_args = ("gloo", n, 16, 0, 0x5EED0004, 1 << 14, n // (2 * world) if world == 2 else 1 << 17, -1)
+    spec_args = ("gloo", n, 16, 0, 0x5EED0004, 1 << 14, {2: n // 4, 3: 1 << 17, 8: n // 8}[world], -1)
     spec = corpus.CorpusSpec(*spec_args)
     want = port.search(spec.host_text(), spec.pattern())
     ctx = mp.get_context("spawn")
@@ -63,6 +64,10 @@ def test_sharded_search_equals_unsharded(world, port):
     # a hit that straddles a shard boundary is reported exactly once, by the left shard
     lo1, _ = shard.shard_bounds(n, world, 1)
     assert any(p < lo1 < p + 16 for p in want.tolist())
+    if world == 8:
+        for r in range(1, 8):
+            cut, _ = shard.shard_bounds(n, world, r)
+            assert any(p < cut < p + 16 for p in want.tolist()), r
 
 
 def test_shard_bounds_cover_without_overlap():

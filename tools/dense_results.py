@@ -13,10 +13,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--gib", type=float, default=1.0)
 ap.add_argument("--kind", type=int, default=1, help="1 = ACGT, 0 = printable-95")
 ap.add_argument("--ms", default="1,2,3,4,5,6,8")
+ap.add_argument("--variant", type=int, default=-1, help="an explicit slot of the kernel table (default: the library's own choice)")
 ap.add_argument("--cap", type=int, default=0, help="output capacity (0: room for one match per three positions); small: time the passes without their stores")
 args = ap.parse_args()
 n = int(args.gib * (1 << 30))
 ctx = host.Context(0)
+if args.variant >= 0:
+    ctx.set_variant(args.variant)
 spec = corpus.CorpusSpec("dense", n, 16, kind=args.kind, seed=0x5EED0002)
 d_text = spec.device_text(ctx)
 out = torch.empty(args.cap if args.cap else n // 3 + 1024, dtype=torch.int64, device="cuda")  # room for one match per three positions
@@ -43,7 +46,7 @@ for m in [int(x) for x in args.ms.split(",")]:
     if args.cap:
         ok = None
     w = min(wall[1:])
-    print(json.dumps({"m": m, "matches": int(total), "ascending_and_real": ok, "scan_kernel_ms": round(min(scan[1:]), 3),
+    print(json.dumps({"m": m, "variant": args.variant, "matches": int(total), "ascending_and_real": ok, "scan_kernel_ms": round(min(scan[1:]), 3),
                       "whole_search_ms": round(w, 3), "output_MB": round(total * 8 / 1e6, 1),
                       "hbm_bound_ms_at_5TBps": round((n + total * 8) / 5e12 * 1e3, 3),
                       "text_GBps": round(n / w / 1e6, 1)}), flush=True)
