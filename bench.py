@@ -60,6 +60,10 @@ def parse_args(argv=None):
     ap.add_argument("--gib-per-gpu", type=float, default=4.0)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg3b", "ed64k", "sa2m"])
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--library", default="", help="measurement only: `exp` = libbmx_exp.so (every slot of the kernel table, for "
+                    "--variant), or the path of another build; default: the product library")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
+                    help="measurement only, with --library exp: a switch of bmx_exp_set_knob (e.g. sa_flags=4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=12.0)
     ap.add_argument("--overlap-scans", action="store_true",
@@ -131,6 +135,14 @@ import torch.distributed as dist
 
 from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus, host, shard
 
+def make_context(args, device):
+    c = host.Context(device)
+    for kv in args.knob:
+        name, value = kv.split("=", 1)
+        c.set_knob(name, int(value))
+    return c
+
+
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md:36
 SLOT = 8192             # offsets per rank in the fixed-size all-gather slot (64 KiB)
 
@@ -193,7 +205,7 @@ def bench_edit_distance(args, dev, local_rank):
     rng = np.random.default_rng(0x5EED0005)
     x = (rng.integers(0, 4, n) + 65).astype(np.uint8)
     z = (rng.integers(0, 4, n) + 65).astype(np.uint8)
-    ctx = host.Context(local_rank)
+    ctx = make_context(args, local_rank)
     dx, dz = torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev)
     for _ in range(args.warmup):
         d = ctx.edit_distance_device(dx, dz)
@@ -241,7 +253,7 @@ def bench_suffix_array(args, dev, local_rank):
     para = corpus.stream_bytes(0, 509, 0x5EED0006, 0)  # 509 printable bytes, repeated
     para = np.where(para == 96, 95, para).astype(np.uint8)  # character 96 ties in the reference (bmx.h)
     x = np.tile(para, n // para.size + 1)[:n].copy()
-    ctx = host.Context(local_rank)
+    ctx = make_context(args, local_rank)
     dx = torch.from_numpy(x).to(dev)
     steps = min(args.steps, 50)
     for _ in range(min(args.warmup, 3)):
@@ -279,6 +291,8 @@ def bench_suffix_array(args, dev, local_rank):
 
 def main():
     args = parse_args()
+    if args.library:
+        host.use_library(args.library)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -347,7 +361,7 @@ def main():
     n_lanes = max(1, args.in_flight)
     d_text = None
     for li in range(n_lanes):
-        c = host.Context(local_rank)
+        c = make_context(args, local_rank)
         if args.variant >= 0:
             c.set_variant(args.variant)
         if d_text is None:
@@ -483,7 +497,7 @@ def main():
                   ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process"),
         "config": {"workload": spec.name, "text_bytes_total": spec.n, "text_bytes_per_gpu": n_own,
                    "pattern_bytes": m, "alphabet": "printable-95" if spec.kind == 0 else "ACGT",
-                   "matches": int(result.size), "searches_in_flight": len(lanes), "scans_overlap": bool(args.overlap_scans), "ramp_up_searches": n_ramp,
+                   "matches": int(result.size), "library": args.library or "libbmx.so", "searches_in_flight": len(lanes), "scans_overlap": bool(args.overlap_scans), "ramp_up_searches": n_ramp,
                    "kernel_ms_first_launches": first_ms,
                    "whole_job_GBps_if_scans_may_overlap": None if overlap_value is None else round(overlap_value, 1), "sharding": f"{world} contiguous shard(s) + {m - 1} B halo",
                    "exchange": ("REHEARSAL on one GPU, gloo via host" if rehearse else

@@ -17,6 +17,8 @@
  *                                                  (BoyreMoore/x64/Debug/kernel1.cl:24)
  *   bmx_search_multi      the same, with the text cut over several GPUs (stands where the
  *                         reference cuts it over two work-items, BoyreMoore.cpp:94-141, :273)
+ *   bmx_multi_*           the same host shape kept across searches: devices, communicators and the
+ *                         text stay (the reference sets all of it up per iteration, :217-256)
  *   bmx_search_ranges     kernel1.cl:1 `search(A,B,se,ans,gstable,bstable,sublength)` with the
  *                         launch of BoyreMoore.cpp:264-286: same seven arguments, same per-range
  *                         counts in ans[]
@@ -86,18 +88,57 @@ int bmx_search(bmx_ctx *ctx, const char *text, uint64_t n, const char *pat, int3
 
 /* One process driving several GPUs: the text is cut into n_devices contiguous
  * shards (boundaries on multiples of 16 B, each shard followed by its (m-1)-byte
- * halo; a hit belongs to the shard holding its first byte), shard d is uploaded to
- * and scanned on devices[d] by its own host thread with its own context and
- * stream, and the ascending shard lists are concatenated in shard order -- the
- * global ascending list, identical to bmx_search's.  devices == NULL means
- * 0 .. n_devices-1; a device may be listed more than once (its shards then share
- * it).  Replaces the reference's 2-way split of the text at spaces over two
- * work-items (BoyreMoore.cpp:94-141 + global size 2 at :273), which loses the hits
- * that straddle the cut.  The one-process-per-GPU form of the same cut, with the
- * RCCL exchange, is shard.py / bench.py. */
+ * halo; a hit belongs to the shard holding its first byte), uploaded, searched by
+ * bmx_multi_search below and the global ascending list -- identical to
+ * bmx_search's -- is returned.  devices == NULL means 0 .. n_devices-1; a device
+ * may be listed more than once (its shards then share it and the exchange is
+ * staged through host memory).  The device set of the previous call -- contexts,
+ * streams, the RCCL communicators -- is kept inside the library; the text is
+ * uploaded per call (host buffers in, host buffers out: PCIe-bound by contract).
+ * Replaces the reference's 2-way split of the text at spaces over two work-items
+ * (BoyreMoore.cpp:94-141 + global size 2 at :273), which loses the hits that
+ * straddle the cut. */
 int bmx_search_multi(const char *text, uint64_t n, const char *pat, int32_t m,
                      const int32_t *devices, int32_t n_devices, uint64_t *match_positions,
                      uint64_t capacity, uint64_t *n_matches);
+
+/* ---- one host process, several GPUs, text RESIDENT, one RCCL exchange per search ------- */
+
+/* The reference drives all of its work-items from one C++ main (BoyreMoore.cpp:213-312) and sets
+ * everything up again for every iteration (:217-256).  bmx_multi is that host shape over D devices
+ * with everything kept: per device a context, a stream and the exchange buffers, and ONE RCCL
+ * communicator clique over the listed devices (ncclCommInitAll; librccl is bound at run time).
+ * The text is cut like bmx_search_multi cuts it and stays in HBM; every search is, per device on its
+ * own stream, scan + ordering into a fixed slot [count | 8192 offsets], then ONE ncclAllGather of
+ * the slots inside ncclGroupStart/End (the all-gatherv of match offsets: RCCL has no v-variant),
+ * then a merge kernel that leaves the global ascending list on every device; the host polls device
+ * 0's pinned totals and downloads that list.  A result with more than 8192 matches on some device
+ * is produced exactly (second search into buffers of the counted size, lists concatenated through
+ * the host).  A clique cannot list a device twice: such a set (tests on a 1-GPU box) stages the
+ * slots through host memory instead, everything else being the same code.
+ * The one-process-per-GPU form of the same exchange is shard.py / bench.py. */
+typedef struct bmx_multi bmx_multi;
+int bmx_multi_create(const int32_t *devices, int32_t n_devices, bmx_multi **out);
+void bmx_multi_destroy(bmx_multi *mg);
+int bmx_multi_device_count(const bmx_multi *mg);
+int bmx_multi_uses_rccl(const bmx_multi *mg); /* 1: a real clique; 0: slots staged through host memory */
+/* Make text[0..n) resident, cut over the devices; every shard carries a halo of m_max - 1 bytes, so patterns
+ * of up to m_max bytes can be searched.  Replaces a text made resident before. */
+int bmx_multi_text_upload(bmx_multi *mg, const char *text, uint64_t n, int32_t m_max);
+/* The same with the synthetic corpus of bmx_gen_text_device generated in place, shard by shard, from the
+ * global byte index; bmx_multi_plant copies `pat` over the given GLOBAL offsets (as bmx_plant_device). */
+int bmx_multi_gen_text(bmx_multi *mg, uint64_t n, uint64_t seed, int kind, int32_t m_max);
+int bmx_multi_plant(bmx_multi *mg, const char *pat, int32_t m, const uint64_t *offsets, uint64_t count);
+/* Shard i: out = {first byte, resident bytes, window starts owned}; *d_text_out its device pointer. */
+int bmx_multi_shard(const bmx_multi *mg, int32_t i, uint64_t out[3], void **d_text_out);
+/* (pattern) -> match_positions over the resident text: host array of `capacity` offsets, ascending,
+ * *n_matches the true total (BMX_ERR_CAPACITY if larger). */
+int bmx_multi_search(bmx_multi *mg, const char *pat, int32_t m, uint64_t *match_positions, uint64_t capacity,
+                     uint64_t *n_matches);
+/* Of the most recent bmx_multi_search: the slowest device's scan-kernel time (ms, HIP events), and how the
+ * lists were exchanged: 1 = RCCL all-gather of slots, 2 = slots staged through host memory, 3 = exact path. */
+float bmx_multi_last_scan_ms(bmx_multi *mg);
+int bmx_multi_last_exchange(const bmx_multi *mg);
 
 /* Reference kernel contract: P inclusive ranges se[2P] (int, as the reference),
  * ans[P] = hits whose whole window lies inside the range.  Tables are the
@@ -128,10 +169,10 @@ int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_o
  * work: _enqueue launches scan + ordering on `stream` and returns without
  * synchronising; _finish synchronises, reads the count and orders the rare
  * large result (> BMX_SMALL_SORT matches) with a radix sort.
- * Which walker runs depends on the alphabet of the TEXT: the first search that sees a (d_text, n) pair counts the
- * distinct byte values in four 4 KiB samples (one tiny kernel and one wait of ~20 us on `stream`; skipped while the
- * stream is being captured into a graph, and with BMX_NO_TEXT_SAMPLE=1 in the environment: the pattern's own symbols
- * decide then); every later search refreshes the count in its ordering kernel.  The match list does not depend on it. */
+ * Which walker runs depends on the alphabet of the TEXT: the ordering kernel of every search samples 4 x 256 bytes of
+ * the text it has just scanned and _finish remembers the number of distinct byte values per (d_text, n) pair (the 16
+ * most recent).  The FIRST search on a text therefore goes by the pattern's own symbols and later ones by the text's:
+ * _enqueue never waits for the device.  The match list does not depend on any of it. */
 int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own,
                               uint64_t base_offset, const char *pat, int32_t m,
                               const int32_t *good, const int32_t *bad,

@@ -1,0 +1,30 @@
+/* bmx_exp.h -- entry points that ONLY libbmx_exp.so exports (the same sources as libbmx.so compiled with
+ * -DBMX_EXPERIMENTS: every slot of the kernel table, timing-only kernels, stamp builds).  Measurement and test
+ * infrastructure: tools/ and a few tests bind it (host.exp_lib()); nothing of the product path, bench.py's timed
+ * region or smoke() does.  The product library has none of these and reads no environment variable. */
+#ifndef BMX_EXP_H
+#define BMX_EXP_H
+
+#include "bmx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A measurement / test switch of one context.  Names: "max_grid" (at most n workgroups per scan: texts of a few MiB
+ * then reach the stolen tail), "no_dense" (no fill pass), "no_text_sample" (the walker goes by the pattern's symbols),
+ * "multi_no_qgram" (multi-pattern pass byte-wise only), "ed_lag" (rows a column band is assumed to trail its
+ * predecessor by; < 0: the measured default), "ed_group" (16 | 32 rows per hand-over), "sa_flags" (1 library rounds
+ * only, 2 a host wait per round, 4 per-round trace on stderr).  BMX_ERR_ARG for an unknown name. */
+int bmx_exp_set_knob(bmx_ctx *ctx, const char *name, int value);
+
+/* Read-only sweep of n bytes at d_text (16-byte aligned) with plain global loads into registers, XOR-folded: no LDS,
+ * no barrier, no tiles (csrc/bmx_probe_kernel.h).  unroll = loads in flight per lane (1, 2, 4, 8, 16), nt = cache
+ * policy, block threads per workgroup, blocks_per_cu workgroups per CU.  ms_out[i] = duration of launch i. */
+int bmx_probe_read(bmx_ctx *ctx, const void *d_text, uint64_t n, int block, int blocks_per_cu, int unroll, int nt,
+                   int launches, float *ms_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

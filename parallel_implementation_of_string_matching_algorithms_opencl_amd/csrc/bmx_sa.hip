@@ -494,7 +494,7 @@ __global__ __launch_bounds__(SEG_T, SEG_LOGK == 3 ? 8 : 4) void sa_segsort_kerne
 // *ws / *ws_bytes: the caller's workspace slot (the context keeps it between calls: eight hipMalloc +
 // hipFree per call cost 2 ms next to a 6 ms construction); grown here when too small.
 int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, hipStream_t stream, float *ms_out,
-                              int *rounds_out, void **ws, size_t *ws_bytes, char *err, size_t errlen)
+                              int *rounds_out, void **ws, size_t *ws_bytes, uint32_t **pinned, int switches, char *err, size_t errlen)
 {
     if (ms_out) *ms_out = -1.0f;
     if (rounds_out) *rounds_out = 0;
@@ -554,7 +554,7 @@ int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, 
     // keys[1] / idx[1] hold the suffixes sorted by their first four symbols.  A round (:117 `for (k = 8; k < 2n;
     // k *= 2)`, h = k / 2) = renumber, then order by (rank, rank h further on): in LDS when every group of tied suffixes
     // fits a workgroup's window (sa_segsort_kernel), else through the library sort.
-    const bool debug = getenv("BMX_SA_DEBUG") != nullptr;
+    const bool debug = (switches & 4) != 0;
     uint32_t groups = 0, longest_group = 0;
     uint32_t *const gl = counters + 248; // {groups, longest group} of the library path's renumbering
     auto renumber_from_sorted_keys = [&]() { // :119-140 for the library path: head flags, scan, ranks back to text order
@@ -587,12 +587,12 @@ int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, 
     auto owned = [&]() { return std::max(1024u, std::min(SEG_W - 64u, SEG_W - longest_group)); };
     if (ok()) e = hipMemsetAsync(counters, 0, b_cnt, stream);
     if (ok()) renumber_from_sorted_keys();
-    const bool allow_lds = getenv("BMX_SA_NO_LDS") == nullptr, allow_pipeline = getenv("BMX_SA_NO_PIPELINE") == nullptr;
-    static thread_local uint32_t *hp = nullptr; // pinned: 4 words per round, written by the round's kernel
+    const bool allow_lds = (switches & 1) == 0, allow_pipeline = (switches & 2) == 0;
+    uint32_t *&hp = *pinned; // pinned, owned by the caller's context: 4 words per round, written by the round's kernel
     for (uint64_t k = 8; ok() && groups < n && k < 2 * (uint64_t)n; k *= 2) {
         const uint32_t h = (uint32_t)(k / 2);
         const bool fits = allow_lds && rounds < 30 && longest_group <= SEG_W - 1024;
-        if (fits && allow_pipeline && (hp != nullptr || hipHostMalloc(&hp, 64 * 4 * sizeof(uint32_t)) == hipSuccess)) {
+        if (fits && allow_pipeline && (hp != nullptr || hipHostMalloc(&hp, 64 * 4 * sizeof(uint32_t), hipHostMallocPortable) == hipSuccess)) {
             // From here on every round is an LDS round (groups only split): the rounds are queued back to back and the
             // host looks at a round's counters -- the kernel's last workgroup puts them into pinned memory -- while the
             // NEXT round already runs, instead of synchronising the stream after every round.  The round that turns out
@@ -635,7 +635,12 @@ int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, 
             if (pending >= 0 && ok()) look(pending);
             if (ev[0]) (void)hipEventDestroy(ev[0]);
             if (ev[1]) (void)hipEventDestroy(ev[1]);
-            break;
+            // Normally the job is done here.  Should the queue have stopped at its limit of 30 rounds with suffixes still tied
+            // (it cannot for n < 2^31: 30 doublings cover every length), the remaining rounds run the library way instead of
+            // an array that is not fully ordered going out as the answer.
+            if (!(ok() && groups < n && k < 2 * (uint64_t)n)) break;
+            k /= 2; // (the round that has not run yet: the loop header doubles it again)
+            continue;
         }
         if (fits) { // one LDS round, the host waits for it (BMX_SA_NO_PIPELINE, or no pinned memory)
             uint32_t *cnt = counters + 4 * rounds; // {groups after the round, a group was too long for a window, longest group, ticket}

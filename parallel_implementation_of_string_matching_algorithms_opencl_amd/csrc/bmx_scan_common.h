@@ -567,8 +567,8 @@ struct ShortTile {
         first = wave * PIECE + lane * 16;
     }
 
-    // round r: bit j = a match starts at byte j of this lane's chunk
-    __device__ __forceinline__ uint32_t mask(const uint8_t *T, uint32_t r) const
+    // round r: bit j = a match starts at byte j of this lane's chunk (v: the chunk, nx: the four bytes behind it)
+    __device__ __forceinline__ uint32_t mask_of_chunk(const u32x4 v, const uint32_t nx, uint32_t r) const
     {
         // (exact zero-byte test per pattern byte, then the four 0x80 flags of a dword gathered into a nibble by one multiplication)
         auto mask_of = [&](uint32_t cur, uint32_t nxt) -> uint32_t {
@@ -578,8 +578,6 @@ struct ShortTile {
             return (((q >> 7) * 0x00204081u) >> 21) & 0xfu;
         };
         const uint32_t d = first + r * 1024; // (chunks past the piece -- the last round of a 4.25 KiB piece -- are masked off)
-        const u32x4 v = *(lds_c128 *)to_lds(T + d);
-        const uint32_t nx = *(lds_c32 *)to_lds(T + d + 16);
         uint32_t x;
         if (ref != 0) { // (wave-uniform) the usual case
             // v_mqsad_u32_u8: the sums of absolute differences of the reference word against the four 4-byte windows at
@@ -595,26 +593,14 @@ struct ShortTile {
             // add with carry each; written out, hipcc selects constants with a wait state per compare: 48 slots for 32)
             x = 0;
             auto push = [&](uint32_t sum) { asm("v_cmp_eq_u32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : "v"(sum) : "vcc"); };
-            auto pack = [&]() {
 #pragma unroll
-                for (int j = 3; j >= 0; --j) push(r3[j]);
+            for (int j = 3; j >= 0; --j) push(r3[j]);
 #pragma unroll
-                for (int j = 3; j >= 0; --j) push(r2[j]);
+            for (int j = 3; j >= 0; --j) push(r2[j]);
 #pragma unroll
-                for (int j = 3; j >= 0; --j) push(r1[j]);
+            for (int j = 3; j >= 0; --j) push(r1[j]);
 #pragma unroll
-                for (int j = 3; j >= 0; --j) push(r0[j]);
-            };
-            if (sparse) { // (wave-uniform) a large alphabet: a chunk with a match is the exception (printable text, m = 2: one in
-                // 564; m = 3: one in 54,000) -- the smallest of the sixteen sums first, eight v_min3_u32 instead of
-                // the thirty-two instructions above, which only the lanes that hold a match then run
-                auto min3 = [](uint32_t u, uint32_t v, uint32_t w) { uint32_t r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(u), "v"(v), "v"(w)); return r; };
-                const uint32_t a0 = min3(r0.x, r0.y, r0.z), a1 = min3(r0.w, r1.x, r1.y), a2 = min3(r1.z, r1.w, r2.x), a3 = min3(r2.y, r2.z, r2.w);
-                const uint32_t a4 = min3(r3.x, r3.y, r3.z), b0 = min3(a0, a1, a2), b1 = min3(a3, a4, r3.w);
-                if ((b0 < b1 ? b0 : b1) == 0) pack();
-            } else {
-                pack();
-            }
+            for (int j = 3; j >= 0; --j) push(r0[j]);
         } else { // a pattern byte of 0 would be left out of the sums: the zero-byte masks
             x = mask_of(v.x, v.y) | (mask_of(v.y, v.z) << 4) | (mask_of(v.z, v.w) << 8) | (mask_of(v.w, nx) << 12);
         }
@@ -625,15 +611,56 @@ struct ShortTile {
         return x;
     }
 
+    __device__ __forceinline__ uint32_t mask(const uint8_t *T, uint32_t r) const
+    {
+        const uint32_t d = first + r * 1024;
+        const u32x4 v = *(lds_c128 *)to_lds(T + d);
+        const uint32_t nx = *(lds_c32 *)to_lds(T + d + 16);
+        return mask_of_chunk(v, nx, r);
+    }
+
     // this lane's matches among the window starts [lo_t, hi_t) of the tile; the masks stay in e[]
     __device__ __forceinline__ uint32_t count(const LdsTables &tb, const uint8_t *T, uint32_t lo_t, uint32_t hi_t, uint32_t wave,
                                               uint32_t lane, bool sparse_ = false)
     {
         setup(tb, lo_t, hi_t, wave, lane, sparse_);
+        // Every round's chunk is requested before the first is looked at: one LDS latency per tile (several hundred cycles
+        // while the next tile's DMA is landing), not one per round -- round 2 read, waited and tested round by round, and its
+        // stamps put 47 % of a tile period into this walk.
+        u32x4 v[ROUNDS];
+        uint32_t nx[ROUNDS];
+        const uint8_t *base = T + first;
+#pragma unroll
+        for (uint32_t r = 0; r < ROUNDS; ++r) {
+            v[r] = *(lds_c128 *)to_lds(base + r * 1024);
+            nx[r] = *(lds_c32 *)to_lds(base + r * 1024 + 16);
+        }
+        if (sparse && ref != 0) { // (wave-uniform) a large alphabet: a lane with a match in its ROUNDS chunks is the exception
+            // (printable text, m = 2: one lane in 110; m = 3: one in 10,000) -- so first the smallest of all its sums, two
+            // v_min3_u32 per v_mqsad_u32_u8 in four short chains (the quad-SAD skip loop's filter, walk_lane_sad), and the
+            // thirty-two instructions per round that turn sums into a bit mask only in the lanes that hold a match
+            const u32x4 z = {0, 0, 0, 0};
+            uint32_t acc[4] = {~0u, ~0u, ~0u, ~0u};
+#pragma unroll
+            for (uint32_t r = 0; r < ROUNDS; ++r) {
+                const uint32_t w[5] = {v[r].x, v[r].y, v[r].z, v[r].w, nx[r]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u32x4 q = __builtin_amdgcn_mqsad_u32_u8((uint64_t)w[k] | ((uint64_t)w[k + 1] << 32), ref, z);
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[(2 * k) & 3]) : "v"(acc[(2 * k) & 3]), "v"(q.x), "v"(q.y));
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[(2 * k + 1) & 3]) : "v"(acc[(2 * k + 1) & 3]), "v"(q.z), "v"(q.w));
+                }
+            }
+            if (min(min(acc[0], acc[1]), min(acc[2], acc[3])) != 0) {
+#pragma unroll
+                for (uint32_t r = 0; r < ROUNDS; ++r) e[r] = 0;
+                return 0;
+            }
+        }
         uint32_t cnt = 0;
 #pragma unroll
         for (uint32_t r = 0; r < ROUNDS; ++r) {
-            e[r] = mask(T, r);
+            e[r] = mask_of_chunk(v[r], nx[r], r);
             cnt += (uint32_t)__popc(e[r]);
         }
         return cnt;

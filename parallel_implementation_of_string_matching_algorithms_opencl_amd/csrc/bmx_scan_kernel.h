@@ -145,7 +145,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     const uint32_t nchunk = buf_bytes >> 4; // 16-B chunks per tile incl. halo
     // PRIO: the waves that are still issuing their share of the DMA outrank the ones that already walk (the
     // VALU-dense skip loop of older waves otherwise starves the address arithmetic of the younger ones).
-    constexpr bool PRIO = WALK == 7 || WALK == 8 || MODE == 7;
+    constexpr bool PRIO = WALK == 7 || WALK == 8 || WALK == 6 || MODE == 7;
     auto issue_tile = [&](uint64_t t, uint8_t *dst) {
         const uint64_t tile_off = t * (uint64_t)TILE;
         const uint8_t *gsrc = a.text16 + tile_off;

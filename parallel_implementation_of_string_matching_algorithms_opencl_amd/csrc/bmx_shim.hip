@@ -27,6 +27,7 @@
 #include "bmx_scan_ring_kernel.h"
 #include "bmx_scan_wave_kernel.h"
 #ifdef BMX_EXPERIMENTS
+#include "bmx_exp.h"
 #include "bmx_probe_kernel.h"
 #endif
 
@@ -37,7 +38,7 @@ static_assert(bmx::MAX_MULTI == BMX_MAX_MULTI, "header and kernel disagree");
 int bmx_internal_radix_sort(uint64_t *d_keys, uint64_t n, hipStream_t stream, char *err, size_t errlen);
 // bmx_sa.hip
 int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, hipStream_t stream, float *ms_out,
-                              int *rounds_out, void **ws, size_t *ws_bytes, char *err, size_t errlen);
+                              int *rounds_out, void **ws, size_t *ws_bytes, uint32_t **pinned, int flags, char *err, size_t errlen);
 
 namespace {
 
@@ -50,6 +51,13 @@ void set_err(const char *fmt, ...)
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
 }
+
+} // namespace
+
+// for the library's other translation units (bmx_multi.hip): the text bmx_last_error() returns on this thread
+void bmx_internal_set_error(const char *text) { snprintf(g_err, sizeof g_err, "%s", text ? text : ""); }
+
+namespace {
 
 #define HIPCHK(expr)                                                                          \
     do {                                                                                      \
@@ -245,7 +253,16 @@ struct bmx_ctx {
     static constexpr int N_SAMPLED = 16;
     struct { const void *ptr; uint64_t n; int sigma; } sampled[N_SAMPLED] = {};
     unsigned sampled_next = 0;
-    bool text_sample = true; // (libbmx_exp.so can switch it off: the walker then goes by the pattern's symbols)
+    // Measurement / test switches.  Only libbmx_exp.so can change them (bmx_exp_set_knob); in the product library they keep
+    // these values and nothing reads the environment.
+    bool text_sample = true;     // false: the walker goes by the pattern's symbols, not the text's
+    int max_grid = 0;            // > 0: at most this many workgroups per scan (small texts then reach the stolen tail)
+    bool no_dense = false;       // true: no fill pass (a full parking buffer appends the direct way)
+    bool multi_no_qgram = false; // true: the multi-pattern pass walks byte-wise only
+    int ed_lag = 0;              // >= 0 with ed_lag_set: rows a band is assumed to trail its predecessor by
+    bool ed_lag_set = false;
+    int ed_group = 32;           // hand-over group of the band pipeline (16 or 32 rows)
+    int sa_flags = 0;            // suffix array: 1 = library rounds only, 2 = a host wait per round, 4 = per-round trace on stderr
     const void *last_text = nullptr; // the text of the search whose status is awaited (its order_kernel samples it again)
     uint64_t last_text_n = 0;
     int last_variant = 0;    // what the most recent search ran (bmx_scan_geometry reports it)
@@ -257,6 +274,7 @@ struct bmx_ctx {
     float sa_last_ms = -1.0f;
     void *sa_ws = nullptr; // suffix-array workspace, kept between calls while it is small
     size_t sa_ws_bytes = 0;
+    uint32_t *sa_pinned = nullptr; // pinned host block the queued LDS rounds report into (allocated on first use, freed with the context)
     int sa_last_rounds = 0, sa_last_lds_rounds = 0;
     int blocks_per_cu = 0; // 0 = as many as LDS and the 32-wave limit admit
     unsigned long long *d_count = nullptr; // live match counter; re-armed by order_kernel
@@ -397,6 +415,7 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
     if (!ctx->auto_walker) { // an explicitly chosen variant
         const Variant &v = g_variants[ctx->variant];
         if (v.canon_minm && (!canonical || m < v.canon_minm)) return !is_short ? 2 : 0;
+        if (v.canon_minm > 1 && is_short) return 0; // (a q-gram kernel's LDS budget has no room for the short-pattern kernel's parking buffer)
         if (v.canon_minm == 1) *use_short_kernel = false; // the quad-SAD skip loop takes any m
         return lds_bytes_for(v, m) <= LDS_PER_CU ? ctx->variant : 0; // buffers + halo do not fit at this m -> default
     }
@@ -544,6 +563,7 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
     if (ctx->ed_ws) (void)hipFree(ctx->ed_ws);
     if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
+    if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (int i = 0; i < bmx_ctx::EV_RING; ++i) {
         if (ctx->ev0[i]) (void)hipEventDestroy(ctx->ev0[i]);
@@ -698,12 +718,11 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         if (v.kind == 1) nblocks = (nblocks + v.block / 64 - 1) / (v.block / 64); // one piece per wave
         const uint64_t max_grid = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
         uint32_t grid = (uint32_t)std::min<uint64_t>(nblocks, max_grid);
-        if (const char *g = getenv("BMX_MAX_GRID")) // tests: few workgroups, so that a text of a few MiB gives each of them tiles enough for a stolen tail
-            grid = std::min<uint32_t>(grid, (uint32_t)std::max(1, atoi(g)));
+        if (ctx->max_grid > 0) grid = std::min<uint32_t>(grid, (uint32_t)ctx->max_grid); // (libbmx_exp.so only)
 
         // dense results: the scan counts per tile, bmx_search_device_finish runs the fill pass of this geometry
         auto fill = !short_pattern(pat, m) ? v.fill : v.fill_short;
-        if (getenv("BMX_NO_DENSE")) fill = nullptr; // (tools/: A/B runs)
+        if (ctx->no_dense) fill = nullptr; // (libbmx_exp.so only: A/B runs)
         ctx->last_fillable = false;
         if (fill != nullptr && a.stage_cap != 0) a.dense_enabled = 1u | (is_short && sparse ? 2u : 0u); // (count-only calls too: dense tiles are just counted)
         if (fill != nullptr && a.stage_cap != 0 && out != nullptr) {
@@ -950,7 +969,8 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     for (int k = K; k < BMX_MAX_MULTI; ++k) a.multi_off[k] = a.multi_m[k] = 0, a.multi_own_end[k] = 0;
     if (n_starts_max == 0) return BMX_OK;
     if (!ctx->d_multi) HIPCHK(hipMalloc(&ctx->d_multi, MULTI_BLOB_MAX));
-    if (!ctx->d_multi_first) HIPCHK(hipMalloc(&ctx->d_multi_first, (BMX_MAX_MULTI + 1) * sizeof(uint64_t)));
+    constexpr size_t first_bytes = (bmx::MAX_MULTI + 1) * sizeof(uint64_t);
+    if (!ctx->d_multi_first) HIPCHK(hipMalloc(&ctx->d_multi_first, first_bytes));
     HIPCHK(hipMemcpyAsync(ctx->d_multi, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream)); // (the blob is a local)
 
@@ -961,7 +981,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
         HIPCHK(hipMemsetAsync(ctx->d_overflow, 0, 8 * sizeof(uint32_t), stream));
     }
     ctx->armed = false;
-    if (getenv("BMX_MULTI_NO_QGRAM")) qmask = 0; // (tools/: A/B runs)
+    if (ctx->multi_no_qgram) qmask = 0; // (libbmx_exp.so only: A/B runs)
     if (qmask != 0) { // ... and only if the TEXT's alphabet is small (pick_variant)
         const int sigma = text_sigma(ctx, d_text, n);
         if (sigma > 8) qmask = 0;
@@ -1163,8 +1183,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
         ctx->ed_ws_shape[1] = lb;
         ctx->ed_ws_shape[2] = W;
     }
-    int lag = ED_BAND_LAG;
-    if (const char *env = getenv("BMX_ED_LAG")) lag = atoi(env);
+    const int lag = ctx->ed_lag_set ? ctx->ed_lag : ED_BAND_LAG;
     bmx::EdBandArgs a = {};
     a.a = (const uint8_t *)d_a;
     a.b = (const uint8_t *)d_b;
@@ -1192,8 +1211,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        const char *grp = getenv("BMX_ED_GROUP");
-        hipLaunchKernelGGL(grp && atoi(grp) == 16 ? v.band16 : v.band, dim3(2 * bands), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(ctx->ed_group == 16 ? v.band16 : v.band, dim3(2 * bands), dim3(64), 0, stream, a);
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
@@ -1375,8 +1393,8 @@ int bmx_suffix_array_device(bmx_ctx *ctx, const void *d_text, uint64_t n, int32_
     if (!ctx || (n > 0 && (!d_text || !d_sa)) || n >= (1ull << 31)) return BMX_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     const int rc = bmx_internal_suffix_array((const uint8_t *)d_text, (uint32_t)n, d_sa, (hipStream_t)stream_v,
-                                             &ctx->sa_last_ms, &ctx->sa_last_rounds, &ctx->sa_ws, &ctx->sa_ws_bytes, g_err,
-                                             sizeof g_err);
+                                             &ctx->sa_last_ms, &ctx->sa_last_rounds, &ctx->sa_ws, &ctx->sa_ws_bytes, &ctx->sa_pinned,
+                                             ctx->sa_flags, g_err, sizeof g_err);
     ctx->sa_last_lds_rounds = ctx->sa_last_rounds >> 16;
     ctx->sa_last_rounds &= 0xffff;
     if (ctx->sa_ws_bytes > ED_BAND_WS_KEEP) { // a large one is not kept
@@ -1497,100 +1515,7 @@ int bmx_search(bmx_ctx *ctx_in, const char *text, uint64_t n, const char *pat, i
     return rc;
 }
 
-// One process, several GPUs (SURVEY.md s8b "multi-GPU variant may spawn one host thread per
-// device internally"): contiguous shards with 16-B aligned boundaries and an (m-1)-byte halo,
-// a hit is owned by the shard holding its first byte -- the same cut as shard.py makes for
-// the one-process-per-GPU path -- so the shard lists concatenate into the global ascending list.
-int bmx_search_multi(const char *text, uint64_t n, const char *pat, int32_t m, const int32_t *devices,
-                     int32_t n_devices, uint64_t *match_positions, uint64_t capacity, uint64_t *n_matches)
-{
-    if (!pat || m < 1 || m > BMX_MAX_PATTERN || (n > 0 && !text) || n_devices < 1) return BMX_ERR_ARG;
-    if (capacity > 0 && !match_positions) return BMX_ERR_ARG;
-    if (n_matches) *n_matches = 0;
-    int32_t bad[BMX_BAD_TABLE_SIZE];
-    std::vector<int32_t> good(m);
-    int rc = bmx_build_tables(pat, m, bad, good.data());
-    if (rc != BMX_OK) return rc;
-    const int have = bmx_device_count();
-    for (int d = 0; d < n_devices; ++d) {
-        const int dev = devices ? devices[d] : d;
-        if (dev < 0 || dev >= have) {
-            set_err("bmx_search_multi: no HIP device %d (count %d)", dev, have);
-            return BMX_ERR_NO_DEVICE;
-        }
-    }
-    if (n < (uint64_t)m) return BMX_OK;
-
-    struct Shard {
-        int device = 0;
-        uint64_t lo = 0, len = 0, n_own = 0; // resident bytes [lo, lo + len), window starts [lo, lo + n_own)
-        int rc = BMX_OK;
-        uint64_t total = 0;
-        std::vector<uint64_t> hits;
-        std::string err;
-    };
-    const uint64_t D = (uint64_t)n_devices;
-    uint64_t per = (n + D - 1) / D;
-    per = (per + 15) / 16 * 16;
-    std::vector<Shard> shards(n_devices);
-    for (uint64_t d = 0; d < D; ++d) {
-        Shard &s = shards[d];
-        s.device = devices ? devices[d] : (int)d;
-        s.lo = std::min(n, d * per);
-        const uint64_t hi = std::min(n, (d + 1) * per);
-        s.n_own = hi - s.lo;
-        s.len = std::min(n, hi + (uint64_t)m - 1) - s.lo;
-    }
-    auto work = [&](Shard &s) {
-        if (s.len < (uint64_t)m || s.n_own == 0) return; // no whole window starts here
-        bmx_ctx *ctx = nullptr;
-        void *d_text = nullptr;
-        uint64_t *d_out = nullptr;
-        hipStream_t stream = nullptr;
-        const uint64_t dev_cap = std::min<uint64_t>(capacity, std::min(s.n_own, s.len - (uint64_t)m + 1));
-        s.rc = bmx_ctx_create(s.device, &ctx);
-        if (s.rc == BMX_OK && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
-            set_err("bmx_search_multi: stream on device %d", s.device);
-            s.rc = BMX_ERR_HIP;
-        }
-        if (s.rc == BMX_OK) s.rc = bmx_text_upload(ctx, text + s.lo, s.len, &d_text);
-        if (s.rc == BMX_OK && dev_cap) s.rc = bmx_device_alloc(ctx, dev_cap * sizeof(uint64_t), (void **)&d_out);
-        if (s.rc == BMX_OK)
-            s.rc = bmx_search_device(ctx, d_text, s.len, s.n_own, s.lo, pat, m, good.data(), bad, d_out, dev_cap,
-                                     &s.total, stream);
-        if (s.rc == BMX_OK || s.rc == BMX_ERR_CAPACITY) {
-            s.hits.resize(std::min(s.total, dev_cap));
-            if (!s.hits.empty() && hipMemcpy(s.hits.data(), d_out, s.hits.size() * sizeof(uint64_t),
-                                             hipMemcpyDeviceToHost) != hipSuccess) {
-                set_err("bmx_search_multi: download from device %d", s.device);
-                s.rc = BMX_ERR_HIP;
-            }
-        }
-        if (s.rc != BMX_OK) s.err = g_err; // g_err is per thread: hand the text to the caller's thread
-        if (d_out) (void)hipFree(d_out);
-        if (d_text) (void)hipFree(d_text);
-        if (stream) (void)hipStreamDestroy(stream);
-        bmx_ctx_destroy(ctx);
-    };
-    std::vector<std::thread> pool;
-    for (int d = 1; d < n_devices; ++d) pool.emplace_back(work, std::ref(shards[d]));
-    work(shards[0]);
-    for (auto &t : pool) t.join();
-
-    uint64_t total = 0, stored = 0;
-    for (const Shard &s : shards) {
-        if (s.rc != BMX_OK && s.rc != BMX_ERR_CAPACITY) {
-            set_err("%s", s.err.c_str());
-            return s.rc;
-        }
-        total += s.total;
-        const uint64_t take = std::min<uint64_t>(s.hits.size(), capacity - stored);
-        if (take) std::memcpy(match_positions + stored, s.hits.data(), take * sizeof(uint64_t));
-        stored += take;
-    }
-    if (n_matches) *n_matches = total;
-    return total > capacity ? BMX_ERR_CAPACITY : BMX_OK;
-}
+// (bmx_search_multi and the resident multi-GPU search with its RCCL exchange: bmx_multi.hip)
 
 int bmx_search_ranges(bmx_ctx *ctx_in, const char *text, uint64_t n, const char *pat, const int32_t *se,
                       int32_t P, int32_t *ans, const int32_t *good, const int32_t *bad, int32_t m)
@@ -1631,6 +1556,23 @@ int bmx_search_ranges(bmx_ctx *ctx_in, const char *text, uint64_t n, const char 
 }
 
 #ifdef BMX_EXPERIMENTS
+// libbmx_exp.so only: the measurement / test switches of a context (round 2 read them from the environment on every call,
+// in the product library too).  Returns BMX_ERR_ARG for an unknown name.
+int bmx_exp_set_knob(bmx_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name) return BMX_ERR_ARG;
+    const std::string k(name);
+    if (k == "max_grid") ctx->max_grid = value;
+    else if (k == "no_dense") ctx->no_dense = value != 0;
+    else if (k == "no_text_sample") ctx->text_sample = value == 0;
+    else if (k == "multi_no_qgram") ctx->multi_no_qgram = value != 0;
+    else if (k == "ed_lag") ctx->ed_lag = value, ctx->ed_lag_set = value >= 0;
+    else if (k == "ed_group") ctx->ed_group = value;
+    else if (k == "sa_flags") ctx->sa_flags = value;
+    else return BMX_ERR_ARG;
+    return BMX_OK;
+}
+
 // libbmx_exp.so only (tools/hbm_read_probe.py): read-only sweep of n bytes at d_text with plain global loads into
 // registers -- no LDS, no barrier, no tiles (bmx_probe_kernel.h).  `unroll` loads in flight per lane (4, 8, 16), `nt`
 // cache policy, `block` threads per workgroup, `blocks_per_cu` of them per CU.  ms_out[i] = duration of launch i (HIP

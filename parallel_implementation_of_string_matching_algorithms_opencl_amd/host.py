@@ -24,12 +24,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbmx.so")
-# tools/ only: BMX_LIB=exp loads libbmx_exp.so, the same sources built with -DBMX_EXPERIMENTS (losing schedules and
-# timing-only kernels whose match lists are not valid).  Tests, bench.py and smoke() never set it.
-if os.environ.get("BMX_LIB") == "exp":
-    LIB_PATH = os.path.join(_HERE, "lib", "libbmx_exp.so")
-elif os.environ.get("BMX_LIB"):  # an explicit path: A/B runs of an older build on the same box (tools/ only)
-    LIB_PATH = os.environ["BMX_LIB"]
+# libbmx_exp.so: the same sources built with -DBMX_EXPERIMENTS -- every slot of the kernel table (losing schedules, timing-only
+# kernels whose match lists are not valid) and the measurement switches (bmx_exp_set_knob).  tools/ and a few tests load it
+# through exp_lib() / Context(library=exp_lib()); the product path, bench.py and smoke() never do.  Nothing here reads
+# the environment: tools/ that want another build call use_library() themselves.
+EXP_LIB_PATH = os.path.join(_HERE, "lib", "libbmx_exp.so")
 
 MAX_PATTERN = 512
 MAX_MULTI = 8
@@ -56,6 +55,17 @@ SYMBOLS = [
     ("bmx_search", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, C.c_int32, _u64p, C.c_uint64, _u64p]),
     ("bmx_search_multi", C.c_int, [C.c_void_p, C.c_uint64, C.c_char_p, C.c_int32, _i32p, C.c_int32, _u64p, C.c_uint64,
                                    _u64p]),
+    ("bmx_multi_create", C.c_int, [_i32p, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("bmx_multi_destroy", None, [C.c_void_p]),
+    ("bmx_multi_device_count", C.c_int, [C.c_void_p]),
+    ("bmx_multi_uses_rccl", C.c_int, [C.c_void_p]),
+    ("bmx_multi_text_upload", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32]),
+    ("bmx_multi_gen_text", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int32]),
+    ("bmx_multi_plant", C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _u64p, C.c_uint64]),
+    ("bmx_multi_shard", C.c_int, [C.c_void_p, C.c_int32, _u64p, C.POINTER(C.c_void_p)]),
+    ("bmx_multi_search", C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, _u64p, C.c_uint64, _u64p]),
+    ("bmx_multi_last_scan_ms", C.c_float, [C.c_void_p]),
+    ("bmx_multi_last_exchange", C.c_int, [C.c_void_p]),
     ("bmx_search_ranges", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p, _i32p, C.c_int32, _i32p,
                                     _i32p, _i32p, C.c_int32]),
     ("bmx_search_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_char_p,
@@ -101,32 +111,63 @@ class BmxError(RuntimeError):
         super().__init__(f"{what}: {_ERR_NAMES.get(rc, rc)}" + (f" ({detail})" if detail else ""))
 
 
+# entry points only libbmx_exp.so exports
+EXP_SYMBOLS = [
+    ("bmx_exp_set_knob", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    ("bmx_probe_read", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_float), C.c_void_p]),
+]
+
 _lib = None
+_exp = None
+_lib_tolerant = False
+
+
+def _bind(path: str, symbols, tolerant: bool = False):
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C parallel_implementation_of_string_matching_algorithms_opencl_amd/csrc`")
+    L = C.CDLL(path)
+    for name, res, args in symbols:
+        if tolerant and not hasattr(L, name):
+            continue
+        fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def use_library(path: str, tolerant: bool = True) -> None:
+    """tools/ only, before the first call: bind another build of the library (`exp`, or a path -- A/B runs of an older
+    build on the same box; an older build may lack newer entry points, hence tolerant)."""
+    global LIB_PATH, _lib_tolerant
+    if _lib is not None:
+        raise RuntimeError("use_library() must come before the library is first used")
+    LIB_PATH = EXP_LIB_PATH if path == "exp" else path
+    _lib_tolerant = tolerant and path != "exp"
 
 
 def lib():
     """Load libbmx.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise FileNotFoundError(
-                f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C parallel_implementation_of_string_matching_algorithms_opencl_amd/csrc`")
-        L = C.CDLL(LIB_PATH)
-        older_build = os.environ.get("BMX_LIB", "exp") != "exp"  # (tools/ A/B runs: an older build may lack newer entry points)
-        for name, res, args in SYMBOLS:
-            if older_build and not hasattr(L, name):
-                continue
-            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        exp = os.path.abspath(LIB_PATH) == os.path.abspath(EXP_LIB_PATH)
+        _lib = _bind(LIB_PATH, SYMBOLS + (EXP_SYMBOLS if exp else []), _lib_tolerant)
     return _lib
 
 
-def _check(rc: int, what: str, allow=()):
+def exp_lib():
+    """libbmx_exp.so beside the product library in the same process (its own kernels, its own state)."""
+    global _exp
+    if _exp is None:
+        _exp = _bind(EXP_LIB_PATH, SYMBOLS + EXP_SYMBOLS)
+    return _exp
+
+
+def _check(rc: int, what: str, allow=(), L=None):
     if rc != OK and rc not in allow:
-        raise BmxError(rc, what, lib().bmx_last_error().decode(errors="replace"))
+        raise BmxError(rc, what, (L or lib()).bmx_last_error().decode(errors="replace"))
     return rc
 
 
@@ -161,15 +202,23 @@ class Context:
     """One GPU.  Mirrors the reference's per-iteration context/queue
     (BoyreMoore.cpp:217-231) but is created once and reused."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, library=None):
+        self._L = library if library is not None else lib()
         self._h = C.c_void_p()
-        _check(lib().bmx_ctx_create(device, C.byref(self._h)), "bmx_ctx_create")
+        self._chk(self._L.bmx_ctx_create(device, C.byref(self._h)), "bmx_ctx_create")
         self.device = device
+
+    def _chk(self, rc: int, what: str, allow=()):
+        return _check(rc, what, allow, self._L)
 
     def close(self):
         if self._h:
-            lib().bmx_ctx_destroy(self._h)
+            self._L.bmx_ctx_destroy(self._h)
             self._h = C.c_void_p()
+
+    def set_knob(self, name: str, value: int):
+        """libbmx_exp.so only (bmx_exp_set_knob): max_grid, no_dense, no_text_sample, multi_no_qgram, ed_lag, ed_group, sa_flags."""
+        self._chk(self._L.bmx_exp_set_knob(self._h, name.encode(), int(value)), "bmx_exp_set_knob")
 
     def __del__(self):
         try:
@@ -193,11 +242,11 @@ class Context:
         while True:
             out = np.empty(max(cap, 1), dtype=np.uint64)
             total = C.c_uint64(0)
-            rc = lib().bmx_search(self._h, tptr, n, pat, m, out.ctypes.data_as(_u64p), cap, C.byref(total))
+            rc = self._L.bmx_search(self._h, tptr, n, pat, m, out.ctypes.data_as(_u64p), cap, C.byref(total))
             if rc == ERR_CAPACITY and capacity is None:
                 cap = int(total.value)
                 continue
-            _check(rc, "bmx_search")
+            self._chk(rc, "bmx_search")
             del keep
             return out[: int(total.value)].copy()
 
@@ -214,7 +263,7 @@ class Context:
             bad = np.ascontiguousarray(bad, dtype=np.int32)
             good = np.ascontiguousarray(good, dtype=np.int32)
             gp, bp = good.ctypes.data_as(_i32p), bad.ctypes.data_as(_i32p)
-        _check(lib().bmx_search_ranges(self._h, tptr, n, pat, se.ctypes.data_as(_i32p), P,
+        self._chk(self._L.bmx_search_ranges(self._h, tptr, n, pat, se.ctypes.data_as(_i32p), P,
                                        ans.ctypes.data_as(_i32p), gp, bp, len(pat)), "bmx_search_ranges")
         return ans[:P].copy()
 
@@ -243,9 +292,9 @@ class Context:
             gp, bp = good.ctypes.data_as(_i32p), bad.ctypes.data_as(_i32p)
         stream = C.c_void_p(torch.cuda.current_stream(d_text.device).cuda_stream)
         total = C.c_uint64(0)
-        rc = lib().bmx_search_device(self._h, C.c_void_p(d_text.data_ptr()), n, n_own, base_offset, pat, m, gp, bp,
+        rc = self._L.bmx_search_device(self._h, C.c_void_p(d_text.data_ptr()), n, n_own, base_offset, pat, m, gp, bp,
                                      C.c_void_p(out.data_ptr()), cap, C.byref(total), stream)
-        _check(rc, "bmx_search_device", allow=(ERR_CAPACITY,))
+        self._chk(rc, "bmx_search_device", allow=(ERR_CAPACITY,))
         return out[: min(int(total.value), cap)], int(total.value)
 
     def search_device_multi(self, d_text, patterns, *, n: Optional[int] = None, n_own: Optional[int] = None,
@@ -268,9 +317,9 @@ class Context:
         counts = (C.c_uint64 * K)()
         first = (C.c_uint64 * K)()
         stream = C.c_void_p(torch.cuda.current_stream(d_text.device).cuda_stream)
-        rc = lib().bmx_search_device_multi(self._h, C.c_void_p(d_text.data_ptr()), n, n_own, base_offset, arr, ms, K,
+        rc = self._L.bmx_search_device_multi(self._h, C.c_void_p(d_text.data_ptr()), n, n_own, base_offset, arr, ms, K,
                                            C.c_void_p(out.data_ptr()), cap, counts, first, stream)
-        _check(rc, "bmx_search_device_multi")
+        self._chk(rc, "bmx_search_device_multi")
         return [out[int(first[k]): int(first[k]) + int(counts[k])] for k in range(K)]
 
     def enqueue(self, d_text, pattern, out, *, n=None, n_own=None, base_offset=0, tables=None):
@@ -288,7 +337,7 @@ class Context:
             self._keep = (np.ascontiguousarray(bad, dtype=np.int32), np.ascontiguousarray(good, dtype=np.int32))
             bp, gp = self._keep[0].ctypes.data_as(_i32p), self._keep[1].ctypes.data_as(_i32p)
         stream = C.c_void_p(torch.cuda.current_stream(d_text.device).cuda_stream)
-        _check(lib().bmx_search_device_enqueue(self._h, C.c_void_p(d_text.data_ptr()), n, n_own, base_offset, pat,
+        self._chk(self._L.bmx_search_device_enqueue(self._h, C.c_void_p(d_text.data_ptr()), n, n_own, base_offset, pat,
                                                len(pat), gp, bp, C.c_void_p(out.data_ptr()), out.numel(), stream),
                "bmx_search_device_enqueue")
 
@@ -302,8 +351,8 @@ class Context:
 
         stream = C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)
         total = C.c_uint64(0)
-        rc = lib().bmx_search_device_finish(self._h, C.c_void_p(out.data_ptr()), out.numel(), C.byref(total), stream)
-        _check(rc, "bmx_search_device_finish", allow=(ERR_CAPACITY,))
+        rc = self._L.bmx_search_device_finish(self._h, C.c_void_p(out.data_ptr()), out.numel(), C.byref(total), stream)
+        self._chk(rc, "bmx_search_device_finish", allow=(ERR_CAPACITY,))
         return int(total.value)
 
     def count_to_device(self, d_dst):
@@ -311,52 +360,52 @@ class Context:
         import torch
 
         stream = C.c_void_p(torch.cuda.current_stream(d_dst.device).cuda_stream)
-        _check(lib().bmx_count_to_device(self._h, C.c_void_p(d_dst.data_ptr()), stream), "bmx_count_to_device")
+        self._chk(self._L.bmx_count_to_device(self._h, C.c_void_p(d_dst.data_ptr()), stream), "bmx_count_to_device")
 
     def merge_gathered(self, gathered, world: int, slot_stride: int, merged, d_total, seq: int = 0):
         """d_total: 3 x int64, device memory or PINNED host memory (then poll d_total[2] == seq)."""
         import torch
 
         stream = C.c_void_p(torch.cuda.current_stream(gathered.device).cuda_stream)
-        _check(lib().bmx_merge_gathered_device(self._h, C.c_void_p(gathered.data_ptr()), world, slot_stride,
+        self._chk(self._L.bmx_merge_gathered_device(self._h, C.c_void_p(gathered.data_ptr()), world, slot_stride,
                                                C.c_void_p(merged.data_ptr()), merged.numel(),
                                                C.c_void_p(d_total.data_ptr()), seq, stream),
                "bmx_merge_gathered_device")
 
     def last_scan_ms(self) -> float:
-        return float(lib().bmx_last_scan_ms(self._h))
+        return float(self._L.bmx_last_scan_ms(self._h))
 
     def scan_ms_history(self, n: int = 64):
         """Durations (ms) of the most recent scan kernels, newest first (ring of 64)."""
         buf = (C.c_float * max(n, 1))()
-        got = lib().bmx_scan_ms_history(self._h, buf, n)
+        got = self._L.bmx_scan_ms_history(self._h, buf, n)
         if got < 0:
-            raise BmxError(got, "bmx_scan_ms_history", lib().bmx_last_error().decode(errors="replace"))
+            raise BmxError(got, "bmx_scan_ms_history", self._L.bmx_last_error().decode(errors="replace"))
         return [float(buf[i]) for i in range(got)]
 
     def scan_stamps(self, max_words: int = 1 << 16) -> np.ndarray:
         buf = np.zeros(max_words, dtype=np.uint64)
-        got = lib().bmx_scan_stamps(self._h, buf.ctypes.data_as(_u64p), max_words)
+        got = self._L.bmx_scan_stamps(self._h, buf.ctypes.data_as(_u64p), max_words)
         if got < 0:
-            raise BmxError(got, "bmx_scan_stamps", lib().bmx_last_error().decode(errors="replace"))
+            raise BmxError(got, "bmx_scan_stamps", self._L.bmx_last_error().decode(errors="replace"))
         return buf[:got].reshape(-1, 8)
 
     def geometry(self, m: int) -> dict:
         g = (C.c_uint64 * 6)()
-        _check(lib().bmx_scan_geometry(self._h, m, g), "bmx_scan_geometry")
+        self._chk(self._L.bmx_scan_geometry(self._h, m, g), "bmx_scan_geometry")
         return {"grid": int(g[0]), "block": int(g[1]), "tile_bytes": int(g[2]), "lds_bytes": int(g[3]),
                 "seg": int(g[4]), "kind": ("workgroup-tile", "wave-stream", "workgroup-ring")[int(g[5])]}
 
     def stream_wait_last_scan(self, stream) -> None:
         """Make ``stream`` (a torch.cuda.Stream) wait for the scan kernel of this context's latest enqueue."""
-        _check(lib().bmx_stream_wait_last_scan(self._h, C.c_void_p(stream.cuda_stream)), "bmx_stream_wait_last_scan")
+        self._chk(self._L.bmx_stream_wait_last_scan(self._h, C.c_void_p(stream.cuda_stream)), "bmx_stream_wait_last_scan")
 
     def last_search_sorted(self) -> bool:
         """Did the last finish() have to sort (the list was unordered until then)?"""
-        return bool(lib().bmx_last_search_sorted(self._h))
+        return bool(self._L.bmx_last_search_sorted(self._h))
 
     def set_variant(self, variant: int, blocks_per_cu: int = 0):
-        _check(lib().bmx_set_variant(self._h, variant, blocks_per_cu), "bmx_set_variant")
+        self._chk(self._L.bmx_set_variant(self._h, variant, blocks_per_cu), "bmx_set_variant")
 
     # -- edit distance (the reference's second algorithm) --------------------
     def edit_distance(self, a, b) -> int:
@@ -365,7 +414,7 @@ class Context:
         pa, la, ka = _host_text(a)
         pb, lb, kb = _host_text(b)
         d = C.c_uint64(0)
-        _check(lib().bmx_edit_distance(self._h, pa, la, pb, lb, C.byref(d)), "bmx_edit_distance")
+        self._chk(self._L.bmx_edit_distance(self._h, pa, la, pb, lb, C.byref(d)), "bmx_edit_distance")
         return int(d.value)
 
     def edit_distance_device(self, d_a, d_b) -> int:
@@ -373,23 +422,23 @@ class Context:
 
         stream = C.c_void_p(torch.cuda.current_stream(d_a.device).cuda_stream)
         d = C.c_uint64(0)
-        _check(lib().bmx_edit_distance_device(self._h, C.c_void_p(d_a.data_ptr()), d_a.numel(),
+        self._chk(self._L.bmx_edit_distance_device(self._h, C.c_void_p(d_a.data_ptr()), d_a.numel(),
                                               C.c_void_p(d_b.data_ptr()), d_b.numel(), C.byref(d), stream),
                "bmx_edit_distance_device")
         return int(d.value)
 
     def last_edit_distance_ms(self) -> float:
-        return float(lib().bmx_last_edit_distance_ms(self._h))
+        return float(self._L.bmx_last_edit_distance_ms(self._h))
 
     def set_ed_variant(self, v: int):
-        _check(lib().bmx_set_ed_variant(self._h, v), "bmx_set_ed_variant")
+        self._chk(self._L.bmx_set_ed_variant(self._h, v), "bmx_set_ed_variant")
 
     # -- suffix array (the reference's third program) -----------------------------
     def suffix_array(self, text) -> np.ndarray:
         """int32 suffix array in the reference's order (SuffixArrays.cpp:101-154)."""
         pt, n, keep = _host_text(text)
         sa = np.empty(max(n, 1), dtype=np.int32)
-        _check(lib().bmx_suffix_array(self._h, pt, n, sa.ctypes.data_as(_i32p)), "bmx_suffix_array")
+        self._chk(self._L.bmx_suffix_array(self._h, pt, n, sa.ctypes.data_as(_i32p)), "bmx_suffix_array")
         return sa[:n].copy()
 
     def suffix_array_device(self, d_text):
@@ -398,18 +447,18 @@ class Context:
         n = d_text.numel()
         d_sa = torch.empty(max(n, 1), dtype=torch.int32, device=d_text.device)
         stream = C.c_void_p(torch.cuda.current_stream(d_text.device).cuda_stream)
-        _check(lib().bmx_suffix_array_device(self._h, C.c_void_p(d_text.data_ptr()), n, C.c_void_p(d_sa.data_ptr()),
+        self._chk(self._L.bmx_suffix_array_device(self._h, C.c_void_p(d_text.data_ptr()), n, C.c_void_p(d_sa.data_ptr()),
                                              stream), "bmx_suffix_array_device")
         return d_sa[:n]
 
     def last_suffix_array_ms(self) -> float:
-        return float(lib().bmx_last_suffix_array_ms(self._h))
+        return float(self._L.bmx_last_suffix_array_ms(self._h))
 
     def last_suffix_array_rounds(self) -> int:
-        return int(lib().bmx_last_suffix_array_rounds(self._h))
+        return int(self._L.bmx_last_suffix_array_rounds(self._h))
 
     def last_suffix_array_lds_rounds(self) -> int:
-        return int(lib().bmx_last_suffix_array_lds_rounds(self._h))
+        return int(self._L.bmx_last_suffix_array_lds_rounds(self._h))
 
     # -- synthetic corpus in HBM ------------------------------------------
     def gen_text(self, d_dst, start: int, seed: int, kind: int = 0, length: Optional[int] = None):
@@ -417,7 +466,7 @@ class Context:
 
         length = d_dst.numel() if length is None else length
         stream = C.c_void_p(torch.cuda.current_stream(d_dst.device).cuda_stream)
-        _check(lib().bmx_gen_text_device(self._h, C.c_void_p(d_dst.data_ptr()), start, length,
+        self._chk(self._L.bmx_gen_text_device(self._h, C.c_void_p(d_dst.data_ptr()), start, length,
                                          seed & (2**64 - 1), kind, stream), "bmx_gen_text_device")
 
     def plant(self, d_dst, start: int, pattern, offsets, length: Optional[int] = None):
@@ -427,7 +476,7 @@ class Context:
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         length = d_dst.numel() if length is None else length
         stream = C.c_void_p(torch.cuda.current_stream(d_dst.device).cuda_stream)
-        _check(lib().bmx_plant_device(self._h, C.c_void_p(d_dst.data_ptr()), start, length, pat, len(pat),
+        self._chk(self._L.bmx_plant_device(self._h, C.c_void_p(d_dst.data_ptr()), start, length, pat, len(pat),
                                       off.ctypes.data_as(_u64p), off.size, stream), "bmx_plant_device")
 
 
@@ -454,19 +503,94 @@ class PreparedSearch:
         self._total = C.c_uint64(0)
         self._fin_args = (ctx._h, C.c_void_p(out.data_ptr()), C.c_uint64(out.numel()), C.byref(self._total),
                           self._stream)
-        self._enq = lib().bmx_search_device_enqueue
-        self._fin = lib().bmx_search_device_finish
+        self._enq = ctx._L.bmx_search_device_enqueue
+        self._fin = ctx._L.bmx_search_device_finish
 
     def enqueue(self):
         rc = self._enq(*self._enq_args)
         if rc != OK:
-            _check(rc, "bmx_search_device_enqueue")
+            self.ctx._chk(rc, "bmx_search_device_enqueue")
 
     def finish(self) -> int:
         rc = self._fin(*self._fin_args)
         if rc != OK and rc != ERR_CAPACITY:
-            _check(rc, "bmx_search_device_finish")
+            self.ctx._chk(rc, "bmx_search_device_finish")
         return int(self._total.value)
+
+
+class MultiContext:
+    """One host process, several GPUs (bmx_multi_*): devices, communicators and the text stay resident across
+    searches; every search ends with ONE RCCL all-gather of match-offset slots.  ``devices``: a count or a list."""
+
+    EXCHANGE = {0: "none", 1: "rccl all-gather of slots", 2: "slots staged through host memory", 3: "exact (dense result)"}
+
+    def __init__(self, devices: Union[int, Sequence[int]], library=None):
+        self._L = library if library is not None else lib()
+        self._h = C.c_void_p()
+        if isinstance(devices, int):
+            dptr, nd = None, devices
+        else:
+            self._ids = np.ascontiguousarray(devices, dtype=np.int32)
+            dptr, nd = self._ids.ctypes.data_as(_i32p), int(self._ids.size)
+        _check(self._L.bmx_multi_create(dptr, nd, C.byref(self._h)), "bmx_multi_create", L=self._L)
+        self.n_devices = nd
+
+    def close(self):
+        if self._h:
+            self._L.bmx_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self._L.bmx_multi_uses_rccl(self._h))
+
+    def text_upload(self, text, m_max: int):
+        tptr, n, keep = _host_text(text)
+        _check(self._L.bmx_multi_text_upload(self._h, tptr, n, m_max), "bmx_multi_text_upload", L=self._L)
+
+    def gen_text(self, n: int, seed: int, kind: int, m_max: int):
+        _check(self._L.bmx_multi_gen_text(self._h, n, seed & (2**64 - 1), kind, m_max), "bmx_multi_gen_text", L=self._L)
+
+    def plant(self, pattern, offsets):
+        pat = _pat_bytes(pattern)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _check(self._L.bmx_multi_plant(self._h, pat, len(pat), off.ctypes.data_as(_u64p), off.size), "bmx_multi_plant", L=self._L)
+
+    def shard(self, i: int) -> Tuple[int, int, int]:
+        out = (C.c_uint64 * 3)()
+        _check(self._L.bmx_multi_shard(self._h, i, out, None), "bmx_multi_shard", L=self._L)
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def search(self, pattern, capacity: Optional[int] = None) -> np.ndarray:
+        pat = _pat_bytes(pattern)
+        cap = capacity if capacity is not None else 1 << 16
+        while True:
+            out = np.empty(max(cap, 1), dtype=np.uint64)
+            total = C.c_uint64(0)
+            rc = self._L.bmx_multi_search(self._h, pat, len(pat), out.ctypes.data_as(_u64p), cap, C.byref(total))
+            if rc == ERR_CAPACITY and capacity is None:
+                cap = int(total.value)
+                continue
+            _check(rc, "bmx_multi_search", L=self._L)
+            return out[: int(total.value)].copy()
+
+    def last_scan_ms(self) -> float:
+        return float(self._L.bmx_multi_last_scan_ms(self._h))
+
+    def last_exchange(self) -> str:
+        return self.EXCHANGE[int(self._L.bmx_multi_last_exchange(self._h))]
 
 
 _default_ctx: Optional[Context] = None

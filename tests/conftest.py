@@ -68,5 +68,19 @@ def ctx(built):
     c.close()
 
 
+@pytest.fixture()
+def exp_ctx(built):
+    """A context of libbmx_exp.so -- the same sources with the measurement / test switches (bmx_exp_set_knob) that the
+    product library does not have (it reads no environment either): small grids, assumed pipeline lags, ..."""
+    import torch
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import host
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    c = host.Context(0, library=host.exp_lib())
+    yield c
+    c.close()
+
+
 def as_u64(x):
     return np.asarray(x, dtype=np.uint64)

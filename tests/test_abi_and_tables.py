@@ -127,3 +127,21 @@ def test_no_cpu_fallback_without_gpu(built):
     with pytest.raises(host.BmxError) as e:  # the several-GPU entry point does not fall back either
         host.search_multi(b"abcabc", b"abc", 1)
     assert e.value.rc == host.ERR_NO_DEVICE
+
+
+def test_product_library_has_no_environment_switches(built):
+    """Round 2 read BMX_MAX_GRID, BMX_NO_DENSE, BMX_ED_LAG, ... with getenv on every call of the SHIPPED library.  The
+    switches are context fields now and only libbmx_exp.so can set them (bmx_exp_set_knob, include/bmx_exp.h); the product
+    library contains no environment variable name of its own and does not export the experiments' entry points."""
+    blob = open(host.LIB_PATH, "rb").read()
+    assert b"BMX_" not in blob
+    L = C.CDLL(host.LIB_PATH)
+    for name, _, _ in host.EXP_SYMBOLS:
+        assert not hasattr(L, name), name
+    E = C.CDLL(host.EXP_LIB_PATH)
+    for name, _, _ in host.EXP_SYMBOLS:
+        assert hasattr(E, name), name
+    src = open(os.path.join(ROOT, "include", "bmx_exp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    assert sorted(set(re.findall(r"\b(bmx_[a-z0-9_]+)\s*\(", src))) == sorted(n for n, _, _ in host.EXP_SYMBOLS)
+    assert "getenv" not in open(os.path.join(ROOT, host.__name__.split(".")[0], "host.py")).read().replace("os.environ.get", "")

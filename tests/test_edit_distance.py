@@ -112,7 +112,7 @@ def test_gpu_two_ended_schedule_on_every_grid_shape(ctx, port):
 
 
 @pytest.mark.gpu
-def test_gpu_band_pipeline_cut_shapes(ctx, port, monkeypatch):
+def test_gpu_band_pipeline_cut_shapes(exp_ctx, port):
     """The band pipeline's two directions meet on a staircase whose step is set by the assumed
     lag between neighbouring bands: tiny lag = one flat cut row, huge lag = one direction does
     whole bands alone (cut clipped to 0 / lb), in between = a real staircase."""
@@ -120,7 +120,8 @@ def test_gpu_band_pipeline_cut_shapes(ctx, port, monkeypatch):
     shapes = [(1, 1), (70, 300), (300, 70), (257, 256), (256, 257), (1000, 1500), (1500, 1000), (3000, 513),
               (513, 3000), (2048, 2048)]
     for lag in ("0", "3", "64", "200", "700", "100000"):
-        monkeypatch.setenv("BMX_ED_LAG", lag)
+        exp_ctx.set_knob("ed_lag", int(lag))  # (a switch of libbmx_exp.so: the product library assumes its measured lag)
+        ctx = exp_ctx
         for la, lb in shapes:
             x = (rng.integers(0, 3, la) + 97).astype(np.uint8)
             y = (rng.integers(0, 3, lb) + 97).astype(np.uint8)

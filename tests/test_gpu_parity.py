@@ -570,10 +570,10 @@ def test_walker_follows_the_texts_alphabet(built, port):
                 assert c.geometry(m)["tile_bytes"] == tile_bytes, (m, c.geometry(m))
 
 
-def test_stolen_tail_on_small_texts(built, port, monkeypatch):
+def test_stolen_tail_on_small_texts(built, port):
     """The kernels that hand their last tiles out by ticket (variants 53, 54, 79, 82) only do so when a workgroup has
     two dozen tiles and more -- half a GiB of text on 256 CUs, which only the full-size tests reach.  With the grid
-    capped at a few workgroups (BMX_MAX_GRID, a test hook) texts of a few MiB go through the pool: sparse, clustered
+    capped at a few workgroups (the `max_grid` switch of libbmx_exp.so: same sources, same kernels) texts of a few MiB go through the pool: sparse, clustered
     and dense results, a misaligned pointer, shard semantics, a tile count that is no multiple of anything, and twice
     in a row on one context (the ticket counter is re-armed by the ordering kernel) -- against the oracle."""
     import torch
@@ -582,9 +582,9 @@ def test_stolen_tail_on_small_texts(built, port, monkeypatch):
 
     rng = np.random.default_rng(1212)
     out = torch.empty(1 << 22, dtype=torch.int64, device="cuda")
-    for grid in ("3", "5"):
-        monkeypatch.setenv("BMX_MAX_GRID", grid)
-        with host.Context(0) as c:
+    for grid in (3, 5):
+        with host.Context(0, library=host.exp_lib()) as c:
+            c.set_knob("max_grid", grid)
             for variant, alpha, m in ((53, 4, 24), (53, 2, 64), (54, 4, 7), (79, 60, 40), (79, 4, 30), (82, 60, 10), (82, 60, 12)):
                 n = int(rng.integers(9_000_000, 12_000_000))
                 text = (rng.integers(0, alpha, n) + 65).astype(np.uint8)
@@ -604,7 +604,6 @@ def test_stolen_tail_on_small_texts(built, port, monkeypatch):
                 want = port.search(text, pat)
                 want = want[(want >= lo) & (want < lo + own)]
                 assert total == want.size and np.array_equal(pos.cpu().numpy().astype(np.uint64), want), (grid, variant, "shard")
-    monkeypatch.delenv("BMX_MAX_GRID")
 
 
 def test_short_patterns_in_a_shard_view(ctx, port):

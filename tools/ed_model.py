@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from parallel_implementation_of_string_matching_algorithms_opencl_amd import host
 rng = np.random.default_rng(5)
-ctx = host.Context(0)
+ctx = host.Context(0, library=host.exp_lib())  # the lag / group switches exist in libbmx_exp.so only
 lb = 262144
 z = torch.from_numpy((rng.integers(0, 4, lb) + 65).astype(np.uint8)).cuda()
 for v in (0, 2):
@@ -12,7 +12,7 @@ for v in (0, 2):
     for la in (256, 512, 1024, 2048, 4096, 16384):
         x = torch.from_numpy((rng.integers(0, 4, la) + 65).astype(np.uint8)).cuda()
         for lag in (0, 200):
-            os.environ["BMX_ED_LAG"] = str(lag)
+            ctx.set_knob("ed_lag", lag)
             ms = []
             for _ in range(3):
                 d = ctx.edit_distance_device(x, z)

@@ -6,9 +6,9 @@ Prints one JSON line per (block, blocks per CU, loads in flight per lane, cache 
 and next to them the scan kernel's DMA-only build (variant 32) and the product kernel (variant 29) on the same text."""
 import argparse, ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("BMX_LIB", "exp")
 import numpy as np, torch
 from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus, host
+host.use_library(os.environ.get("BMX_LIB", "exp"))  # every slot of the kernel table: libbmx_exp.so (BMX_LIB=<path>: another build, A/B runs)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--gib", type=float, default=4.0)
@@ -20,8 +20,6 @@ spec = corpus.CorpusSpec("probe", n, 16, kind=0, seed=0x5EED0002)
 d_text = spec.device_text(ctx)
 torch.cuda.synchronize()
 L = host.lib()
-L.bmx_probe_read.restype = C.c_int
-L.bmx_probe_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 buf = (C.c_float * args.launches)()
 rows = []

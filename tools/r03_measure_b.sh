@@ -12,9 +12,9 @@ if [ $rc -ge 124 ]; then echo "tests killed ($rc): stop"; exit 1; fi
 timeout -k 10 300 python3 tools/variant_sweep.py --gib 4 --m 16 --kind 0 --rounds 15 --variants 29,30,31,87,88,79,32 > "$OUT/sweep_m16.jsonl" 2> "$OUT/sweep_m16.err" &&
 timeout -k 10 300 python3 tools/variant_sweep.py --gib 4 --m 64 --kind 0 --rounds 10 --variants 29,79,30,31,87,88 > "$OUT/sweep_m64.jsonl" 2> "$OUT/sweep_m64.err" &&
 for v in 29 87 30 88; do
-  BMX_LIB=exp timeout -k 10 200 python3 bench.py --variant $v --steps 200 --warmup 20 --no-cpu-baseline > "$OUT/bench_v$v.json" 2> "$OUT/bench_v$v.err" || exit 1
+  timeout -k 10 200 python3 bench.py --library exp --variant $v --steps 200 --warmup 20 --no-cpu-baseline > "$OUT/bench_v$v.json" 2> "$OUT/bench_v$v.err" || exit 1
 done &&
-BMX_LIB=exp timeout -k 10 200 python3 bench.py --variant 87 --steps 20 --warmup 5 --ramp-up 0 --no-cpu-baseline > "$OUT/bench_v87_cold.json" 2> "$OUT/bench_v87_cold.err" &&
+timeout -k 10 200 python3 bench.py --library exp --variant 87 --steps 20 --warmup 5 --ramp-up 0 --no-cpu-baseline > "$OUT/bench_v87_cold.json" 2> "$OUT/bench_v87_cold.err" &&
 timeout -k 10 400 python3 tools/short_patterns.py --gib 4 --ms 1,2,3,4 --variants auto,0,29,30,87 > "$OUT/short_m1234.jsonl" 2> "$OUT/short_m1234.err" &&
 timeout -k 10 400 python3 tools/short_patterns.py --gib 4 --ms 5,6,8,10,12 --variants auto,30,87,88 > "$OUT/short_m5_12.jsonl" 2> "$OUT/short_m5_12.err" &&
 timeout -k 10 200 python3 tools/stamp_report.py --gib 4 --m 2 --variant 84 > "$OUT/stamps_v84_m2.txt" 2>&1 &&

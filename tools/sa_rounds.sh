@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 out=gpurun_out/sa_trace
 rm -rf "$out"; mkdir -p "$out"
-BMX_SA_DEBUG=1 rocprofv3 --kernel-trace --output-format csv -d "$out" -- python3 bench.py --workload sa2m --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/sa_trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$out" -- python3 bench.py --workload sa2m --steps 1 --warmup 1 --no-cpu-baseline --library exp --knob sa_flags=4 > gpurun_out/sa_trace.log 2>&1
 python3 - "$out" <<'PY' > gpurun_out/sa_rounds.txt
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]

@@ -2,9 +2,9 @@
     python tools/stamp_report.py --m 16 --kind 0"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("BMX_LIB", "exp")  # every slot of the kernel table: libbmx_exp.so (the product library refuses the others)
 import numpy as np, torch
 from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus, host
+host.use_library(os.environ.get("BMX_LIB", "exp"))  # every slot of the kernel table: libbmx_exp.so (BMX_LIB=<path>: another build, A/B runs)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--gib", type=float, default=4.0)

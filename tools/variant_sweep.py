@@ -11,12 +11,12 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("BMX_LIB", "exp")  # every slot of the kernel table: libbmx_exp.so (the product library refuses the others)
 
 import numpy as np
 import torch
 
 from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus, host
+host.use_library(os.environ.get("BMX_LIB", "exp"))  # every slot of the kernel table: libbmx_exp.so (BMX_LIB=<path>: another build, A/B runs)
 
 
 def main():

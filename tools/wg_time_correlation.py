@@ -3,9 +3,9 @@
     python tools/wg_time_correlation.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("BMX_LIB", "exp")
 import numpy as np, torch
 from parallel_implementation_of_string_matching_algorithms_opencl_amd import corpus, host
+host.use_library(os.environ.get("BMX_LIB", "exp"))  # every slot of the kernel table: libbmx_exp.so (BMX_LIB=<path>: another build, A/B runs)
 
 spec = corpus.CorpusSpec("stamps", 4 << 30, 16, kind=0, seed=0x5EED0002)
 ctx = host.Context(0)
