@@ -261,6 +261,8 @@ int bmx_scan_stamps(bmx_ctx *ctx, uint64_t *out, uint64_t max_words);
  * with BMX_ERR_ARG.  bmx_variant_count() = number of slots (built or not). */
 int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu);
 int bmx_variant_count(void);
+/* The slot of the kernel table that the most recent search on ctx ran (what the automatic choice picked). */
+int bmx_last_variant(bmx_ctx *ctx);
 
 /* ---- edit distance: the reference's second algorithm ------------ */
 

@@ -19,9 +19,10 @@
 //                             of the runs and the distance, :358-383)
 //   bmx_cli --suffix-array F [--iters N] [--max-print K]   its third (SuffixArrays.cpp: text from
 //                             input.txt, :181; array printed, :155-161; mean time, :514)
-//           [--gpus G]        also run the search over G GPUs from this one process
-//                             (bmx_search_multi: G shards, one host thread each) and
-//                             check its list against the one-GPU list
+//           [--gpus G]        also run the search over G GPUs from this one process: devices, RCCL
+//                             communicators and the text set up once (bmx_multi_*), `iters` searches on
+//                             the resident shards, each list checked against the one-GPU list; then once
+//                             through the host-buffer entry point bmx_search_multi
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -235,19 +236,51 @@ int main(int argc, char **argv)
         printf("Average time = %.6f s  (%.3f GB/s)\n", avg, avg > 0 ? (double)n / avg / 1e9 : 0.0);
     }
 
-    if (gpus > 0) { // host buffers in and out: upload + scan + download per call, over `gpus` devices
+    if (gpus > 0) {
+        // The same search from this ONE host process over `gpus` devices (the reference drives all of its work-items from
+        // one main, BoyreMoore.cpp:273-286): devices, RCCL communicators and the text are set up once (bmx_multi_*), then
+        // `iters` searches run on the resident shards, each ending with one all-gather of match-offset slots.
         std::vector<uint64_t> one(n_matches ? n_matches : 1), many(n_matches ? n_matches : 1);
         uint64_t got1 = 0, gotN = 0;
         rc = bmx_search(ctx, text.data(), n, pat.data(), m, one.data(), one.size(), &got1);
+        if (rc != BMX_OK) {
+            fprintf(stderr, "bmx_search failed: %d (%s)\n", rc, bmx_last_error());
+            return 1;
+        }
+        bmx_multi *mg = nullptr;
+        rc = bmx_multi_create(nullptr, gpus, &mg);
+        if (rc == BMX_OK) rc = bmx_multi_text_upload(mg, text.data(), n, m);
+        if (rc != BMX_OK) {
+            fprintf(stderr, "bmx_multi over %d GPUs: set-up failed: %d (%s)\n", gpus, rc, bmx_last_error());
+            return 1;
+        }
+        double total_multi = 0.0;
+        for (int it = 0; it < iters; ++it) {
+            auto t0 = std::chrono::steady_clock::now();
+            rc = bmx_multi_search(mg, pat.data(), m, many.data(), many.size(), &gotN);
+            auto t1 = std::chrono::steady_clock::now();
+            if (rc != BMX_OK) {
+                fprintf(stderr, "bmx_multi_search over %d GPUs failed: %d (%s)\n", gpus, rc, bmx_last_error());
+                return 1;
+            }
+            total_multi += std::chrono::duration<double>(t1 - t0).count();
+        }
+        const char *how[] = {"none", "RCCL all-gather of slots", "slots staged through host memory", "exact path (dense result)"};
+        bool same = got1 == gotN && std::equal(one.begin(), one.begin() + got1, many.begin());
+        printf("%d GPUs, resident shards: %llu occurrences, average time = %.6f s (slowest scan kernel %.3f ms, exchange: %s), list %s the one-GPU list\n",
+               gpus, (unsigned long long)gotN, iters > 0 ? total_multi / iters : 0.0, bmx_multi_last_scan_ms(mg),
+               how[bmx_multi_last_exchange(mg) & 3], same ? "identical to" : "DIFFERS from");
+        bmx_multi_destroy(mg);
+        if (!same) return 1;
+        // ... and through the host-buffer entry point (upload + search + download per call)
         auto t0 = std::chrono::steady_clock::now();
-        if (rc == BMX_OK)
-            rc = bmx_search_multi(text.data(), n, pat.data(), m, nullptr, gpus, many.data(), many.size(), &gotN);
+        rc = bmx_search_multi(text.data(), n, pat.data(), m, nullptr, gpus, many.data(), many.size(), &gotN);
         auto t1 = std::chrono::steady_clock::now();
         if (rc != BMX_OK) {
             fprintf(stderr, "bmx_search_multi over %d GPUs failed: %d (%s)\n", gpus, rc, bmx_last_error());
             return 1;
         }
-        const bool same = got1 == gotN && std::equal(one.begin(), one.begin() + got1, many.begin());
+        same = got1 == gotN && std::equal(one.begin(), one.begin() + got1, many.begin());
         printf("%d GPUs, host buffers in and out: %llu occurrences in %.6f s, list %s the one-GPU list\n", gpus,
                (unsigned long long)gotN, std::chrono::duration<double>(t1 - t0).count(),
                same ? "identical to" : "DIFFERS from");

@@ -79,6 +79,7 @@ struct ScanArgs {
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef volatile __attribute__((address_space(3))) uint32_t lds_u32; // explicit LDS accesses (ds_*), never flat_*
+typedef volatile __attribute__((address_space(3))) uint64_t lds_u64;
 typedef const __attribute__((address_space(1))) void gbl_void;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -139,10 +140,11 @@ struct LdsTables {
     const uint8_t *qtab;  // QGRAM_TABLE x u8, q-gram walkers only (shifts above 255 are stored as 255: a shorter shift is a safe one)
     uint32_t bm[4];       // bitmap walker: bit c set iff character c occurs in the pattern (scalar copies)
     const uint8_t *bad8;  // 256 x u8 copy of bad[] (m <= 255): 64 LDS words = 2 per bank instead of 4
-    lds_u32 *stage;       // the workgroup's parking buffer for the tile being walked: tile-local window starts
+    lds_u64 *stage;       // the workgroup's ACTIVE parking buffer: window starts in aligned coordinates (bits 56.. the pattern's
+                          // number in a multi-pattern pass), of as many tiles as it takes to half-fill it (scan_body)
     lds_u32 *stage_cnt;   // running count of matches sent to this buffer (never reset: stage_seen is subtracted)
-    uint32_t stage_seen;  // its value when this tile's walk began
-    lds_u32 *stage_area;  // [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
+    uint32_t stage_seen;  // its value when the buffer last became the active one (was last emptied)
+    lds_u32 *stage_area;  // [buffer 0 | buffer 1 (8-byte entries) | count 0 | count 1 | flag | - | base lo | base hi]
     lds_u32 *fill_area;   // fill pass, m = 1..3: 1 KiB per wave (the parking area's place: nothing is parked in that pass)
     uint32_t stage_cap;   // entries per buffer
     uint32_t pat_id;      // which pattern of a multi-pattern pass these tables belong to (else 0): bits 20.. of a parked entry
@@ -190,9 +192,9 @@ __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &t
             const uint32_t addr = (uint32_t)(uintptr_t)tb.stage_cnt, n = (uint32_t)__popcll(active);
             asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(addr), "v"(n) : "memory");
         }
-        base = __shfl(base, leader) - tb.stage_seen; // matches parked for this tile before mine
+        base = __shfl(base, leader) - tb.stage_seen; // matches parked in this buffer before mine
         if (base + rank < tb.stage_cap) {
-            tb.stage[base + rank] = (uint32_t)(astart - tile_off) | (tb.pat_id << 20); // (a tile has fewer than 2^20 window starts)
+            tb.stage[base + rank] = astart | ((uint64_t)tb.pat_id << 56);
             return;
         }
         // The buffer is full: this tile is dense.  Its matches have all been COUNTED (the counter above), which
@@ -205,18 +207,16 @@ __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &t
     emit_hit(a, astart - a.first, astart + a.out_bias, tb.stage_cap == 0, tb.pat_id);
 }
 
-// Second half of an append (all threads of the workgroup, `n` > 0 matches of the tile at `tile_off`
-// parked in `buf`): thread 0 publishes the base its global atomic returned -- issued before this tile's
-// DMA, consumed here, after the walk, when the wait for it costs nothing that the loop's own wait for
-// the DMA would not cost anyway -- everybody else waits for it on an LDS flag, then the workgroup
-// stores the offsets.  Position buckets (the sort-free ordering of sparse results) are fed by a tile with
-// up to 16 matches; with more the workgroup declares them overflowed (results that dense outgrow them
-// anyway) and the list is ordered by a sort.
+// Second half of an append (all threads of the workgroup; `n` > 0 matches parked in `buf`, which is no longer the active
+// buffer): thread 0 publishes the base its global atomic returned -- issued a tile period earlier, consumed here, after
+// a walk -- everybody else waits for it on an LDS flag, then the workgroup stores the offsets.  Position buckets (the
+// sort-free ordering of sparse results) are fed while the workgroup's matches so far, times the number of workgroups,
+// still fit them; denser results declare them overflowed and the list is ordered by a sort / written by the fill pass.
 template <uint32_t BLOCK>
-__device__ __forceinline__ void finish_parked(const ScanArgs &a, const LdsTables &tb, uint64_t tile_off, lds_u32 *buf,
-                                              uint32_t n, unsigned long long reserved, uint32_t ticket)
+__device__ __forceinline__ void finish_parked(const ScanArgs &a, const LdsTables &tb, lds_u64 *buf, uint32_t n,
+                                              unsigned long long reserved, uint32_t ticket, bool buckets)
 {
-    lds_u32 *flag = tb.stage_area + 2 * tb.stage_cap + 2, *base_w = tb.stage_area + 2 * tb.stage_cap + 4;
+    lds_u32 *flag = tb.stage_area + 4 * tb.stage_cap + 2, *base_w = tb.stage_area + 4 * tb.stage_cap + 4;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) {
         base_w[0] = (uint32_t)reserved;
@@ -242,17 +242,14 @@ __device__ __forceinline__ void finish_parked(const ScanArgs &a, const LdsTables
     }
     if (a.out == nullptr) return;
     const unsigned long long base = ((unsigned long long)base_w[1] << 32) | base_w[0];
-    // a position bucket is at least as long as a tile (texts of 0.5 GiB and more) and holds 8: a tile with
-    // more than 16 matches overflows its one or two buckets for certain
-    const bool buckets = n <= 2u * ORDER_BUCKET_CAP;
     if (!buckets && tid == 0) *a.bucket_overflow = 1u;
     for (uint32_t j = tid; j < n; j += BLOCK) {
-        const uint32_t entry = buf[j];
-        const uint64_t astart = tile_off + (entry & 0xFFFFFu);
+        const uint64_t entry = buf[j];
+        const uint64_t astart = entry & 0x00FFFFFFFFFFFFFFull;
         const uint64_t pos = astart + a.out_bias;
         if (base + j < a.cap) a.out[base + j] = pos; // (unordered; in a multi-pattern pass only the bucket path below counts)
         if (buckets) {
-            const uint32_t b = (entry >> 20) * a.bucket_stride + (uint32_t)((astart - a.first) >> a.bucket_shift);
+            const uint32_t b = (uint32_t)(entry >> 56) * a.bucket_stride + (uint32_t)((astart - a.first) >> a.bucket_shift);
             const uint32_t slot = atomicAdd(&a.bucket_cnt[b], 1u);
             if (slot < (uint32_t)ORDER_BUCKET_CAP)
                 a.bucket_store[(uint64_t)b * ORDER_BUCKET_CAP + slot] = pos;
@@ -438,46 +435,6 @@ __device__ __forceinline__ void walk_lane_qgram8(const ScanArgs &a, const LdsTab
     }
 }
 
-// ---- byte-wise walker behind a register bitmap -------------------------------------------------
-// walk_lane<false> pays two dependent LDS reads per window: the window's last character, then its shift.  On
-// a large alphabet most windows end in a character that does not occur in the pattern at all (printable text,
-// m = 16: 85 %) and the shift is simply m: a 128-bit set of the pattern's characters in four scalar registers
-// answers that with a handful of VALU instructions, and the table in LDS is only read for the other windows.
-// Same windows, same shifts as walk_lane<false>.
-__device__ __forceinline__ void walk_lane_bitmap(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
-                                                 uint32_t hi, uint64_t tile_off)
-{
-    const uint32_t m = tb.m;
-    uint32_t i = lo + m - 1;
-    const uint32_t ilim = hi + m - 1;
-    const uint32_t plast = tb.pat[m - 1];
-    const uint64_t set_lo = (uint64_t)tb.bm[0] | ((uint64_t)tb.bm[1] << 32), set_hi = (uint64_t)tb.bm[2] | ((uint64_t)tb.bm[3] << 32);
-    while (i < ilim) {
-        const uint32_t c = T[i];
-        const uint64_t set = (c & 64u) ? set_hi : set_lo;
-        if (c >= 128u || ((set >> (c & 63u)) & 1ull) == 0) { // not a character of the pattern: bad[c] == m (kernel1.cl:28,30)
-            i += m;
-            continue;
-        }
-        const uint32_t b = tb.bad[c];
-        if (c != plast) {
-            i += b;
-            continue;
-        }
-        uint32_t k = 1; // kernel1.cl:20-22
-        while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
-        if (k == m) { // kernel1.cl:24
-            const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-            report_hit(a, tb, astart, tile_off);
-            i += 1;
-            continue;
-        }
-        const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28
-        const int d2 = (int)tb.good[k];                             // kernel1.cl:29
-        i += (uint32_t)(d1 > d2 ? d1 : d2);                         // kernel1.cl:31
-    }
-}
-
 // ---- m = 1..3: compare every position, four at a time ---------------------------------------
 // With m <= 3 the shift tables cannot skip anything worth the two dependent LDS reads per window
 // (printable text, m = 2: 34 rounds per 68-byte segment).  The same windows are tested here from
@@ -635,27 +592,35 @@ struct ShortTile {
             v[r] = *(lds_c128 *)to_lds(base + r * 1024);
             nx[r] = *(lds_c32 *)to_lds(base + r * 1024 + 16);
         }
-        if (sparse && ref != 0) { // (wave-uniform) a large alphabet: a lane with a match in its ROUNDS chunks is the exception
-            // (printable text, m = 2: one lane in 110; m = 3: one in 10,000) -- so first the smallest of all its sums, two
-            // v_min3_u32 per v_mqsad_u32_u8 in four short chains (the quad-SAD skip loop's filter, walk_lane_sad), and the
-            // thirty-two instructions per round that turn sums into a bit mask only in the lanes that hold a match
+        if (sparse && ref != 0) { // (wave-uniform) a large alphabet: a chunk with a match is the exception
+            // (printable text, m = 2: one chunk in 564; m = 3: one in 54,000) -- so first the smallest of a chunk's sixteen
+            // sums, two v_min3_u32 per v_mqsad_u32_u8 in two short chains (the quad-SAD skip loop's filter, walk_lane_sad),
+            // every round's before any is looked at; the thirty-two instructions per round that turn sums into a bit
+            // mask then only run for the rounds -- and in the lanes -- that hold a match (m = 2: one wave round in nine)
             const u32x4 z = {0, 0, 0, 0};
-            uint32_t acc[4] = {~0u, ~0u, ~0u, ~0u};
+            uint32_t mn[ROUNDS];
 #pragma unroll
             for (uint32_t r = 0; r < ROUNDS; ++r) {
                 const uint32_t w[5] = {v[r].x, v[r].y, v[r].z, v[r].w, nx[r]};
+                uint32_t acc[2] = {~0u, ~0u};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const u32x4 q = __builtin_amdgcn_mqsad_u32_u8((uint64_t)w[k] | ((uint64_t)w[k + 1] << 32), ref, z);
-                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[(2 * k) & 3]) : "v"(acc[(2 * k) & 3]), "v"(q.x), "v"(q.y));
-                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[(2 * k + 1) & 3]) : "v"(acc[(2 * k + 1) & 3]), "v"(q.z), "v"(q.w));
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[0]) : "v"(acc[0]), "v"(q.x), "v"(q.y));
+                    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[1]) : "v"(acc[1]), "v"(q.z), "v"(q.w));
+                }
+                mn[r] = acc[0] < acc[1] ? acc[0] : acc[1];
+            }
+            uint32_t cnt = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < ROUNDS; ++r) {
+                e[r] = 0;
+                if (mn[r] == 0) { // (per lane; the wave skips the block when no lane is in it)
+                    e[r] = mask_of_chunk(v[r], nx[r], r);
+                    cnt += (uint32_t)__popc(e[r]);
                 }
             }
-            if (min(min(acc[0], acc[1]), min(acc[2], acc[3])) != 0) {
-#pragma unroll
-                for (uint32_t r = 0; r < ROUNDS; ++r) e[r] = 0;
-                return 0;
-            }
+            return cnt;
         }
         uint32_t cnt = 0;
 #pragma unroll
@@ -690,7 +655,7 @@ __device__ __forceinline__ uint32_t park_tile_short(const ScanArgs &a, const Lds
     }
     uint32_t base = 0;
     if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(addr), "v"(total) : "memory");
-    base = __builtin_amdgcn_readfirstlane(base) - tb.stage_seen; // matches of this tile counted before this wave's
+    base = __builtin_amdgcn_readfirstlane(base) - tb.stage_seen; // matches counted in this buffer before this wave's
     const bool fits = base + total <= tb.stage_cap;
     if (!fits && a.dense_enabled != 0) return total;
     uint32_t idx = base + (incl - cnt);
@@ -701,7 +666,7 @@ __device__ __forceinline__ uint32_t park_tile_short(const ScanArgs &a, const Lds
         while (x != 0) {
             const uint32_t j = (uint32_t)(__ffs((int)x) - 1);
             if (fits || idx < tb.stage_cap) {
-                tb.stage[idx] = p0 + j; // (pattern 0: the multi-pattern pass has its own kernel)
+                tb.stage[idx] = tile_off + (uint64_t)(p0 + j); // (pattern 0: the multi-pattern pass has its own kernel)
             } else {
                 const uint64_t astart = tile_off + (uint64_t)(p0 + j);
                 emit_hit(a, astart - a.first, astart + a.out_bias, false, 0);
@@ -790,78 +755,6 @@ __device__ __forceinline__ void fill_tile_short(const ScanArgs &a, const LdsTabl
     }
 }
 
-// ---- byte-wise walker on the 8-bit copy of the bad-symbol table (m <= 255) ------------------
-__device__ __forceinline__ void walk_lane_b8(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
-                                             uint32_t hi, uint64_t tile_off)
-{
-    const uint32_t m = tb.m;
-    uint32_t i = lo + m - 1;
-    const uint32_t ilim = hi + m - 1;
-    const uint32_t plast = tb.pat[m - 1];
-    while (i < ilim) {
-        const uint32_t c = T[i];
-        const uint32_t b = tb.bad8[c];
-        if (c != plast) {
-            i += b;
-            continue;
-        }
-        uint32_t k = 1;
-        while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
-        if (k == m) {
-            const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-            report_hit(a, tb, astart, tile_off);
-            i += 1;
-            continue;
-        }
-        const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1;
-        const int d2 = (int)tb.good[k];
-        i += (uint32_t)(d1 > d2 ? d1 : d2);
-    }
-}
-
-// ---- byte-wise walker, two windows in flight -----------------------------------------------
-// The walk is a chain of dependent LDS reads (text byte -> shift -> next text byte).  On a large
-// alphabet most windows end in a character that is not in the pattern and shift by the full m
-// (printable-95, m = 16: 83 %), so the window after next is usually the one at i + m: its last
-// character and shift are read TOGETHER with the current ones and used when the guess was right.
-// Same windows, same shifts as walk_lane<false>; only the order of the LDS reads differs.
-__device__ __forceinline__ void walk_lane_spec(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
-                                               uint32_t hi, uint64_t tile_off)
-{
-    const uint32_t m = tb.m;
-    uint32_t i = lo + m - 1;
-    const uint32_t ilim = hi + m - 1;
-    const uint32_t plast = tb.pat[m - 1];
-    while (i < ilim) {
-        uint32_t c = T[i];
-        const uint32_t c2 = T[i + m]; // may lie past this lane's windows (never past the workgroup's LDS): unused then
-        uint32_t b = tb.bad[c];
-        const uint32_t b2 = tb.bad[c2];
-        if (c != plast) { // k == 0: shift = bad[c] (kernel1.cl:28,30)
-            i += b;
-            if (b != m || i >= ilim) continue;
-            // the guess was right: the window at i is the one whose last character is c2
-            if (c2 != plast) {
-                i += b2;
-                continue;
-            }
-            c = c2;
-            b = b2;
-        }
-        uint32_t k = 1; // kernel1.cl:20-22
-        while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
-        if (k == m) { // kernel1.cl:24
-            const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-            report_hit(a, tb, astart, tile_off);
-            i += 1;
-            continue;
-        }
-        const int d1 = (int)b - (int)k > 1 ? (int)b - (int)k : 1; // kernel1.cl:28
-        const int d2 = (int)tb.good[k];                             // kernel1.cl:29
-        i += (uint32_t)(d1 > d2 ? d1 : d2);                         // kernel1.cl:31
-    }
-}
-
 // ---- skip loop by quad-SAD: the walk without a dependency chain --------------------------------
 // The walkers above advance through a chain of dependent LDS reads (text byte -> shift -> next text
 // byte, ~100-150 cycles per link with 16 waves on the CU), and the workgroup waits at the tile barrier
@@ -889,14 +782,15 @@ __device__ __forceinline__ void walk_lane_spec(const ScanArgs &a, const LdsTable
 
 constexpr uint32_t SAD_SEG = 80; // filter positions (bytes) per lane: 16 x odd
 
+// The stops among the filter positions [s_lo, s_hi) of a lane (a multiple of 4 apart, 16-byte aligned start).  next_ok: the
+// first window start the reference's loop could visit next (carried from one piece of the lane's positions to the next).
 template <bool F8>
-__device__ __forceinline__ void verify_stops(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t sbeg,
-                                             uint32_t o, uint32_t lo_t, uint32_t hi_t, uint64_t tile_off, uint32_t ref_a,
-                                             uint32_t ref_b)
+__device__ __forceinline__ void verify_stops(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t s_lo, uint32_t s_hi,
+                                             uint32_t o, uint32_t &next_ok, uint32_t hi_t, uint64_t tile_off, uint32_t ref_a,
+                                             uint32_t ref_b, uint32_t k0)
 {
     const uint32_t m = tb.m;
-    uint32_t next_ok = lo_t; // first window start the reference's loop could visit next
-    for (uint32_t s = sbeg; s < sbeg + SAD_SEG; s += 4) {
+    for (uint32_t s = s_lo; s < s_hi; s += 4) {
         lds_c32 *q = (lds_c32 *)to_lds(T + s);
         const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
         const u32x4 z = {0, 0, 0, 0};
@@ -913,7 +807,9 @@ __device__ __forceinline__ void verify_stops(const ScanArgs &a, const LdsTables 
             const uint32_t p = s + j - o; // window start (wraps to a huge value for stops before the tile's first window)
             if (p >= hi_t || p < next_ok) continue;
             const uint32_t i = p + m - 1; // kernel1.cl:15: index of the window's last character
-            uint32_t k = 0;               // kernel1.cl:20-22
+            // kernel1.cl:20-22.  A sum of 0 against a reference word without a zero byte IS the equality of the window's
+            // last F characters (all of them, for a pattern shorter than F): the comparison goes on from there
+            uint32_t k = k0;
             while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
             if (k == m) { // kernel1.cl:24
                 report_hit(a, tb, tile_off + (uint64_t)p, tile_off);
@@ -953,8 +849,10 @@ __device__ __forceinline__ void walk_lane_sad(const ScanArgs &a, const LdsTables
         d[20] = v.x, d[21] = v.y;
     }
     const u32x4 z = {0, 0, 0, 0};
-    uint32_t acc[4] = {~0u, ~0u, ~0u, ~0u}; // four short chains of v_min3_u32 (as asm: hipcc otherwise re-associates
-                                            // them into three instructions per four windows instead of two)
+    // Two short chains of v_min3_u32 per QUARTER of the lane's positions (as asm: hipcc otherwise re-associates them into
+    // three instructions per four windows instead of two): a lane that stops only goes over the quarters that hold a stop
+    // again (round 2 kept four chains over everything and re-did all twenty groups).
+    uint32_t acc[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
 #pragma unroll
     for (int k = 0; k < 20; ++k) {
         u32x4 r;
@@ -964,11 +862,25 @@ __device__ __forceinline__ void walk_lane_sad(const ScanArgs &a, const LdsTables
         } else {
             r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d[k] | ((uint64_t)d[k + 1] << 32), ref_a, z);
         }
-        asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[(2 * k) & 3]) : "v"(acc[(2 * k) & 3]), "v"(r.x), "v"(r.y));
-        asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[(2 * k + 1) & 3]) : "v"(acc[(2 * k + 1) & 3]), "v"(r.z), "v"(r.w));
+        asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[2 * (k / 5)]) : "v"(acc[2 * (k / 5)]), "v"(r.x), "v"(r.y));
+        asm("v_min3_u32 %0, %1, %2, %3" : "=v"(acc[2 * (k / 5) + 1]) : "v"(acc[2 * (k / 5) + 1]), "v"(r.z), "v"(r.w));
     }
-    if (min(min(acc[0], acc[1]), min(acc[2], acc[3])) != 0) return; // no window of this lane's ends like the pattern
-    verify_stops<F8>(a, tb, T, sbeg, o, lo_t, hi_t, tile_off, ref_a, ref_b);
+    const uint32_t q0 = min(acc[0], acc[1]), q1 = min(acc[2], acc[3]), q2 = min(acc[4], acc[5]), q3 = min(acc[6], acc[7]);
+    if (min(min(q0, q1), min(q2, q3)) != 0) return; // no window of this lane's ends like the pattern
+    // does a sum of 0 prove the equality of the bytes it covers?  (a reference byte of 0 is left out of the sums)
+    auto no_zero_byte = [](uint32_t w, uint32_t bytes) {
+        bool ok = true;
+        for (uint32_t i = 0; i < bytes; ++i) ok = ok && ((w >> (8 * i)) & 0xffu) != 0;
+        return ok;
+    };
+    const uint32_t covered = m < F ? m : F;
+    const bool exact = m < 4 ? no_zero_byte(ref_a, m) : (no_zero_byte(ref_a, 4) && (!F8 || no_zero_byte(ref_b, 4)));
+    const uint32_t k0 = exact ? covered : 0u; // (wave-uniform)
+    uint32_t next_ok = lo_t;
+    if (q0 == 0) verify_stops<F8>(a, tb, T, sbeg, sbeg + 20, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
+    if (q1 == 0) verify_stops<F8>(a, tb, T, sbeg + 20, sbeg + 40, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
+    if (q2 == 0) verify_stops<F8>(a, tb, T, sbeg + 40, sbeg + 60, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
+    if (q3 == 0) verify_stops<F8>(a, tb, T, sbeg + 60, sbeg + 80, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
 }
 
 // wait until at most n of this wave's vector-memory operations are outstanding
@@ -1057,18 +969,19 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
     tb.pat_id = 0;
     tb.lane_cnt = 0;
     tb.write_at = 0;
-    // parking area for matches: [buffer 0 | buffer 1 | count 0 | count 1 | flag | - | base lo | base hi]
+    // parking area for matches: [buffer 0 | buffer 1 (8-byte entries) | count 0 | count 1 | flag | - | base lo | base hi]
     tb.stage_cap = a.stage_cap;
-    tb.stage = tb.stage_cnt = tb.stage_area = nullptr;
+    tb.stage = nullptr;
+    tb.stage_cnt = tb.stage_area = nullptr;
     tb.fill_area = (lds_u32 *)to_lds(end);
     tb.stage_seen = 0;
     if (a.stage_cap != 0) {
         lds_u32 *area = (lds_u32 *)to_lds(end);
         tb.stage_area = area;
-        tb.stage = area;
-        tb.stage_cnt = area + 2 * a.stage_cap;
-        if (tid < 2) area[2 * a.stage_cap + tid] = 0;        // the counters
-        if (tid == 2) area[2 * a.stage_cap + 2] = 0xFFFFFFFFu; // no ticket yet
+        tb.stage = (lds_u64 *)area;
+        tb.stage_cnt = area + 4 * a.stage_cap;
+        if (tid < 2) area[4 * a.stage_cap + tid] = 0;        // the counters
+        if (tid == 2) area[4 * a.stage_cap + 2] = 0xFFFFFFFFu; // no ticket yet
     }
     tb.m = m;
     tb.m4 = m >= 4;

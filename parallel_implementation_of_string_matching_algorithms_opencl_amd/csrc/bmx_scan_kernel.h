@@ -31,6 +31,9 @@
 #include <type_traits>
 
 #include "bmx_scan_common.h"
+#ifdef BMX_EXPERIMENTS
+#include "bmx_scan_exp_walkers.h"
+#endif
 
 namespace bmx {
 
@@ -83,6 +86,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     static_assert(GRADE == 0 || (BLOCK == 1024 && LOADERS == 0 && WALK != 7 && WALK != 8), "");
     static_assert(GRADE == 0 || grade_seg(GRADE, 0, 0) + grade_seg(GRADE, 1, 0) + grade_seg(GRADE, 2, 0) + grade_seg(GRADE, 3, 0) == 4 * SEG,
                   "a graded split keeps the tile size");
+#ifndef BMX_EXPERIMENTS
+    // libbmx.so instantiates the product's kernels and nothing else: the scan (MODE 0; 12 with a stolen tail), the fill
+    // pass's two launches (10, 9), the walkers the automatic choice can pick, no loader waves, no graded shares.  Every
+    // other branch below is dead in the product and only exists in libbmx_exp.so.
+    static_assert(MODE == 0 || MODE == 9 || MODE == 10 || MODE == 12, "experiment build only");
+    static_assert(WALK == 0 || WALK == 2 || WALK == 3 || WALK == 6 || WALK == 7 || WALK == 8 || WALK == 10 || WALK == 20 || WALK == 21, "experiment build only");
+    static_assert(LOADERS == 0 && SEGI == 0 && GRADE == 0, "experiment build only");
+#endif
     static_assert(SEG % 4 == 0 && (SEG / 4) % 2 == 1, "SEG must be 4 * odd (LDS bank spread)");
     static_assert(BLOCK % 64 == 0, "whole waves");
     constexpr int NL = LOADERS < 0 ? -LOADERS : LOADERS; // loader waves
@@ -225,9 +236,22 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     }
     uint32_t it = 0; // tiles walked so far by this workgroup
     uint32_t short_wc = 0; // WALK 6: matches this wave counted in the tile it walked last (wave-uniform)
-    uint32_t seen[2] = {0, 0}; // the parking buffers' counts as of their last collection
-    auto park_buf = [&](uint32_t p) { return tb.stage_area + p * tb.stage_cap; };
-    auto park_cnt = [&](uint32_t p) { return tb.stage_area + 2 * tb.stage_cap + p; };
+    // The parking ledger.  Matches are parked in the ACTIVE one of two LDS buffers -- not tile by tile, as round 2 did, but
+    // for as many tiles as it takes to half-fill it -- and a buffer is emptied into HBM (ONE global atomic reserves its
+    // slots, then the workgroup stores) a tile period after it stopped being the active one.  With one match per MiB (the
+    // bench corpus: 16 matches per workgroup and launch) that is once, at the end; round 2 paid a reservation and a
+    // collection in every tile period that followed a tile with a match, two exposed round trips (~3.8 us) which a walk
+    // of ~3,000 cycles hid and the quad-SAD skip loop's ~1,500 did not: 0.605 ms without matches, 0.665 with the corpus's
+    // 4,161 (steady protocol, one box).
+    // (Few loop-carried scalars, none of them a vector register: a reservation's result that lives across the loop's back
+    // edge gets an `s_waitcnt vmcnt(0)` in front of its copy on EVERY period -- i.e. a wait for the tile DMA in flight:
+    // the first version of this ledger ran the byte-wise kernel at 0.77 instead of 0.65 ms that way.)
+    uint32_t ab = 0;            // the active buffer (bit 0); bit 1: a half-full buffer has gone out already
+    uint32_t ep_act = 0;        // the active buffer's counter when it last became active (its entries: counter - ep_act)
+    uint32_t ep_oth = 0;        // ... the other buffer's counter, which stands still until that one is active again
+    uint32_t last_now = 0;      // the active buffer's counter at the previous period's top (per-tile counts)
+    auto park_buf = [&](uint32_t p) { return (lds_u64 *)(tb.stage_area + p * 2u * tb.stage_cap); };
+    auto park_cnt = [&](uint32_t p) { return tb.stage_area + 4 * tb.stage_cap + p; };
     if (t < t_end && issues) issue_tile(t, buf0);
     uint32_t cur = 0;
     // MODE 5: where does a tile period go?  s_memtime stamps, summed per wave (the
@@ -289,7 +313,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         // (the count of the previous tile's parked matches is requested from LDS before the DMA issue and
         // looked at after it: a read that is waited for on the spot costs every wave ~150 cycles per tile)
         uint32_t parked_now = 0;
-        if (MODE != 1 && tb.stage_cap != 0 && it != 0) parked_now = *park_cnt((it & 1u) ^ 1u);
+        if (MODE != 1 && tb.stage_cap != 0 && it != 0) parked_now = *park_cnt(ab & 1u);
         if constexpr (ST) {
             // the tile AFTER tn comes out of the pool (tn is the last of the static share, or a pool tile itself): ask now,
             // IN FRONT of the DMA issue -- the issue holds a wave for 1500-3000 cycles, a head start the request can use
@@ -306,37 +330,44 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         if constexpr (WALK == 6 && SCAN_MODE)
             if (a.wave_count != nullptr && it != 0 && lane == 0)
                 a.wave_count[((ST ? t_prev : t - t_step) - a.tile_begin) * (uint64_t)NW + wave] = short_wc;
-        // Matches parked while the PREVIOUS tile was walked: reserve their slots now (one global atomic by
-        // one thread, not waited for; after the DMA issue, which must not wait for the LDS read here), park
-        // this tile's matches in the other buffer meanwhile.
-        uint32_t prev_n = 0;
-        unsigned long long reserved = 0;
+        // The ledger's bookkeeping for the PREVIOUS tile (one LDS word, requested above): its match count, and whether
+        // the active buffer is due.  Nothing here touches global memory unless a buffer goes out.
+        uint32_t fl_n = 0, fl_buf = 0; // a buffer on its way out in THIS period: entries, which one
+        unsigned long long fl_reserved = 0;
         if (MODE != 1 && tb.stage_cap != 0) {
-            // The counters only ever grow (nobody resets them, so nobody can reset them too early): what a
-            // buffer received for its last tile is its count now minus its count when that walk began.  Every
-            // wave reads the same count here -- the next match goes to this buffer two barriers from now.
-            const uint32_t pp = (it & 1u) ^ 1u;
+            // The counters only ever grow (nobody resets them, so nobody can reset them too early).  Every wave reads
+            // the same count here -- the next match is parked two barriers from now.
             if (it != 0) {
                 const uint32_t now = __builtin_amdgcn_readfirstlane(parked_now);
-                const uint32_t n_true = now - seen[pp]; // every match of that tile was counted, parked or not
-                seen[pp] = now;
-                if constexpr (WALK == 6 && SCAN_MODE) // m = 1..3: the fill pass (dense results) starts from these counts
+                const uint32_t n_true = now - last_now; // every match of that tile was counted, parked or not
+                last_now = now;
+                if constexpr (WALK == 6 && SCAN_MODE) // m = 1..4: the fill pass (dense results) starts from these counts
                     if (a.tile_count != nullptr && tid == 0) a.tile_count[(ST ? t_prev : t - t_step) - a.tile_begin] = n_true;
-                if (dense_mode && (wg_dense || n_true > tb.stage_cap)) { // (wave-uniform: tb.sink is a per-lane state)
-                    // a dense tile: nothing of it is stored -- the fill pass will write the whole list -- and from here
-                    // on this workgroup only counts (per lane, one LDS add per wave and tile instead of one per event);
-                    // the count goes to the device counter when the workgroup is done (no global access here)
-                    dense_total += n_true;
+                const uint32_t fill = now - ep_act; // entries of the active buffer (counted; stored as far as they fit)
+                if (dense_mode && (wg_dense || fill > tb.stage_cap)) { // (wave-uniform: tb.sink is a per-lane state)
+                    // the buffer overflowed: a dense tile.  Nothing of it is stored -- the fill pass will write the whole
+                    // list -- and from here on this workgroup only counts (per lane, one LDS add per wave and tile instead
+                    // of one per event); the count goes to the device counter when the workgroup is done
+                    dense_total += wg_dense ? n_true : fill;
+                    ep_act = now;
                     tb.sink = 1;
                     wg_dense = true;
-                } else {
-                    prev_n = n_true < tb.stage_cap ? n_true : tb.stage_cap;
-                    if (prev_n != 0 && tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
+                } else if (fill >= (tb.stage_cap + 1) / 2) {
+                    // half full: this buffer goes out -- its slots are reserved now (one global atomic by one thread, behind
+                    // the DMA issue, not waited for), it is emptied after this period's walk -- and the other one takes over
+                    fl_n = fill < tb.stage_cap ? fill : tb.stage_cap; // (without a fill pass what did not fit went the direct way)
+                    fl_buf = ab & 1u;
+                    if (tid == 0) fl_reserved = atomicAdd(a.count, (unsigned long long)fl_n);
+                    const uint32_t e = ep_oth; // (a buffer's counter stands still while it is not the active one)
+                    ep_oth = now;
+                    ep_act = e;
+                    last_now = e;
+                    ab = (ab ^ 1u) | 2u;
                 }
             }
-            tb.stage = park_buf(it & 1u);
-            tb.stage_cnt = park_cnt(it & 1u);
-            tb.stage_seen = seen[it & 1u];
+            tb.stage = park_buf(ab & 1u);
+            tb.stage_cnt = park_cnt(ab & 1u);
+            tb.stage_seen = ep_act;
         }
 
         if (MODE == 5) {
@@ -393,12 +424,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                     walk_lane_qgram(a, tb, T, lo, hi, tile_off);
                 else if constexpr (WALK == 10)
                     walk_lane_qgram8(a, tb, T, lo, hi, tile_off);
+#ifdef BMX_EXPERIMENTS
                 else if constexpr (WALK == 9)
                     walk_lane_bitmap(a, tb, T, lo, hi, tile_off);
                 else if constexpr (WALK == 4)
                     walk_lane_spec(a, tb, T, lo, hi, tile_off);
                 else if constexpr (WALK == 5)
                     walk_lane_b8(a, tb, T, lo, hi, tile_off);
+#endif
                 else if constexpr (WALK == 6)
                     walk_lane_short(a, tb, T, lo, hi, tile_off);
                 else
@@ -473,8 +506,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             }
         }
         if (issue_now && issue_late) issue_tile(tn, cur ? buf0 : buf1);
-        if (prev_n != 0) // the previous tile's matches: reserved before this tile's DMA, stored now
-            finish_parked<BLOCK>(a, tb, (ST ? t_prev : t - t_step) * (uint64_t)TILE, park_buf((it & 1u) ^ 1u), prev_n, reserved, it);
+        if (fl_n != 0) // a buffer on its way out: reserved before this tile's walk, stored now.  (A result that fills buffers
+                       // is past what the position buckets can order: they are declared overflowed.)
+            finish_parked<BLOCK>(a, tb, park_buf(fl_buf), fl_n, fl_reserved, it, false);
         ++it;
         if (MODE == 5) {
             const unsigned long long x = stamp();
@@ -493,25 +527,27 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     } else {
         for (; t < t_end; t += t_step) period(std::false_type{});
     }
-    if (MODE != 1 && tb.stage_cap != 0 && it != 0) { // what the last tile left parked
+    if (MODE != 1 && tb.stage_cap != 0 && it != 0) { // the last tile's count, and what is still parked
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        const uint32_t pp = (it & 1u) ^ 1u;
-        const uint32_t n_true = __builtin_amdgcn_readfirstlane(*park_cnt(pp)) - seen[pp];
+        const uint32_t now = __builtin_amdgcn_readfirstlane(*park_cnt(ab & 1u));
+        const uint32_t n_true = now - last_now;
         if constexpr (WALK == 6 && SCAN_MODE)
             if (a.wave_count != nullptr && lane == 0) a.wave_count[((STEAL ? t_prev : t - t_step) - a.tile_begin) * (uint64_t)NW + wave] = short_wc;
         if constexpr (WALK == 6 && SCAN_MODE)
             if (a.tile_count != nullptr && tid == 0) a.tile_count[(STEAL ? t_prev : t - t_step) - a.tile_begin] = n_true;
-        if (dense_mode && (wg_dense || n_true > tb.stage_cap)) {
-            dense_total += n_true;
+        const uint32_t fill = now - ep_act;
+        if (dense_mode && (wg_dense || fill > tb.stage_cap)) {
+            dense_total += wg_dense ? n_true : fill;
             wg_dense = true;
-        } else {
-            const uint32_t prev_n = n_true < tb.stage_cap ? n_true : tb.stage_cap;
-            if (prev_n != 0) {
-                unsigned long long reserved = 0;
-                if (tid == 0) reserved = atomicAdd(a.count, (unsigned long long)prev_n);
-                finish_parked<BLOCK>(a, tb, (STEAL ? t_prev : t - t_step) * (uint64_t)TILE, park_buf(pp), prev_n, reserved, it);
-            }
+        } else if (fill != 0) {
+            const uint32_t n_out = fill < tb.stage_cap ? fill : tb.stage_cap;
+            unsigned long long reserved = 0;
+            if (tid == 0) reserved = atomicAdd(a.count, (unsigned long long)n_out);
+            // the position buckets (the sort-free ordering) take what a workgroup still holds at its end, if no buffer of its
+            // has filled up before and all workgroups together, at this one's rate, stay within them
+            const bool buckets = (ab & 2u) == 0 && (uint64_t)n_out * gridDim.x <= (uint64_t)ORDER_BUCKETS * 4u;
+            finish_parked<BLOCK>(a, tb, park_buf(ab & 1u), n_out, reserved, it, buckets);
         }
     }
     if constexpr (STEAL)

@@ -24,9 +24,9 @@
 #include "bmx_aux_kernels.h"
 #include "bmx_ed_band_kernel.h"
 #include "bmx_ed_kernel.h"
+#ifdef BMX_EXPERIMENTS
 #include "bmx_scan_ring_kernel.h"
 #include "bmx_scan_wave_kernel.h"
-#ifdef BMX_EXPERIMENTS
 #include "bmx_exp.h"
 #include "bmx_probe_kernel.h"
 #endif
@@ -103,11 +103,6 @@ struct Variant {
 // bmx_set_variant() refuses a slot that is not built: no caller of the shipped C ABI can select a kernel
 // that returns a wrong match list (tests/test_gpu_parity.py::test_product_library_accepts_only_its_variants).
 #define BMX_ABSENT {0, 0, 0, 0, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
-#ifdef BMX_EXPERIMENTS
-#define BMX_EXP(...) __VA_ARGS__
-#else
-#define BMX_EXP(...) BMX_ABSENT
-#endif
 #define BMX_TILE(B, S, AUX, MODE, W) BMX_TILE_L(B, S, AUX, MODE, W, 0)
 #define BMX_TILE_L(B, S, AUX, MODE, W, L) BMX_TILE_LS(B, S, AUX, MODE, W, L, 0)
 #define BMX_TILE_LS(B, S, AUX, MODE, W, L, SI) BMX_TILE_G(B, S, AUX, MODE, W, L, SI, 0)
@@ -140,106 +135,23 @@ struct Variant {
     {2, B, S, 3, 0, 0, (MODE) == 5, (W) == 10, (W) == 10 ? 8 : 0, bmx::scan_ring_kernel<B, S, AUX, W, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, 0, MODE, P>, nullptr, nullptr, nullptr, nullptr}
 #define BMX_WAVE(WV, S, AUX, MODE, D, NB)                                                      \
     {1, (WV) * 64, S, NB, 0, 0, false, false, 0, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, nullptr, nullptr, nullptr, nullptr}
-const Variant g_variants[] = {
-    BMX_TILE_F(1024, 68, 2, 0),                  // 0: PRODUCT -- 16 waves share a 68 KiB tile, nt DMA, byte-wise walker
-                                                 //    (the automatic choice for m < 4 and for dense small-alphabet results)
-    BMX_TILE_F(1024, 68, 2, 2),                  // 1: PRODUCT -- same tile, skip-loop walker
-    BMX_TILE_W32(1024, 36, 2, 0, 2),             // 2: PRODUCT -- skip-loop walker, 36 KiB tiles, TWO workgroups = 32 waves
-                                                 //    per CU (picked automatically for small alphabets, m < 10)
-    BMX_EXP(BMX_TILE(768, 100, 2, 0, 0)),        // 3
-    BMX_EXP(BMX_TILE(256, 132, 2, 0, 0)),        // 4: two workgroups per CU
-    BMX_EXP(BMX_TILE(256, 132, 0, 0, 0)),        // 5: default cache policy -- the first kernel of round 1
-    BMX_EXP(BMX_WAVE(16, 68, 2, 0, 2, 2)),       // 6: wave streams, two buffers per wave, speculation depth 2
-    BMX_EXP(BMX_WAVE(8, 100, 2, 0, 2, 3)),       // 7: wave streams, three buffers per wave
-    BMX_EXP(BMX_WAVE(12, 68, 2, 0, 1, 3)),       // 8: wave streams, no speculation
-    BMX_EXP(BMX_RING(1024, 52, 2, false, 0)),    // 9: three-buffer ring, walk then issue
-    BMX_EXP(BMX_RING(1024, 52, 2, true, 0)),     // 10: ring, skip-loop walker
-    BMX_EXP(BMX_TILE_L(1024, 76, 2, 0, 0, 2)),   // 11: 2 loader waves + 14 walker waves
-    // ---- timing experiments (parts of the kernel in isolation; match lists are NOT valid) ----
-    BMX_EXP(BMX_TILE(1024, 68, 2, 1, 0)),        // 12: DMA only
-    BMX_EXP(BMX_TILE(1024, 68, 2, 2, 0)),        // 13: walkers only
-    BMX_EXP(BMX_TILE(1024, 68, 2, 5, 0)),        // 14: s_memtime stamps per tile phase (valid matches; bmx_scan_stamps)
-    BMX_EXP(BMX_RING(1024, 52, 2, false, 5)),    // 15: stamps, ring kernel
-    BMX_EXP(BMX_WAVE(8, 100, 2, 1, 2, 3)),       // 16: DMA only, wave streams
-    BMX_EXP(BMX_WAVE(8, 100, 2, 2, 2, 3)),       // 17: walkers only, wave streams
-    BMX_EXP(BMX_TILE(1024, 68, 2, 3, 0)),        // 18: only wave 0 of each workgroup walks
-    BMX_EXP(BMX_TILE_L(1024, 68, 2, 1, 0, 1)),   // 19: DMA only through ONE loader wave
-    // ---- more geometries / walkers with valid match lists ----
-    BMX_EXP(BMX_TILE(512, 68, 2, 0, 0)),         // 20: two workgroups of 8 waves per CU, 34 KiB tiles
-    BMX_EXP(BMX_TILE(512, 76, 2, 0, 0)),         // 21: same, 38 KiB tiles
-    BMX_EXP(BMX_TILE(512, 132, 2, 0, 0)),        // 22: one workgroup of 8 waves, 66 KiB tiles
-    BMX_EXP(BMX_TILE_W32(1024, 36, 2, 0, 0)),    // 23: variant 2's geometry with the byte-wise walker
-    BMX_TILE_F(1024, 68, 2, 3),                  // 24: PRODUCT -- default geometry, 4-gram walker (picked automatically for
-                                                 //     small alphabets, m >= 10)
-    BMX_TILE_F(1024, 36, 2, 3),                  // 25: PRODUCT -- 4-gram walker, 36 KiB tiles, two workgroups per CU
-    BMX_EXP(BMX_TILE(1024, 68, 2, 0, 4)),        // 26: default geometry, byte-wise walker with two windows in flight
-    BMX_EXP(BMX_TILE(1024, 68, 2, 0, 5)),        // 27: byte-wise walker on an 8-bit bad-symbol table (m <= 255 only)
-    BMX_EXP(BMX_TILE(1024, 68, 2, 6, 0)),        // 28: default kernel, half of the waves issue their DMA share AFTER their walk
-    BMX_TILE_F(1024, 76, 2, 0),                  // 29: PRODUCT -- 76 KiB tiles, room for 512 parked matches only (picked
-                                                 //     automatically for patterns over more than 8 distinct symbols, m >= 4)
-    BMX_EXP(BMX_TILE(1024, 76, 2, 0, 7)),        // 30: 76 KiB tiles, quad-SAD skip loop on the last 4 pattern bytes (valid lists; slower: DESIGN.md s5.4)
-    BMX_EXP(BMX_TILE(1024, 76, 2, 0, 8)),        // 31: the same on the last 8 pattern bytes (m >= 8)
-    BMX_EXP(BMX_TILE(1024, 76, 2, 1, 0)),        // 32: DMA only, 76 KiB tiles (timing; no valid match list)
-    BMX_EXP(BMX_TILE(1024, 76, 2, 5, 7)),        // 33: stamps, quad-SAD skip loop (last 4)
-    BMX_EXP(BMX_TILE(1024, 76, 2, 5, 0)),        // 34: stamps, 76 KiB tiles, byte-wise walker
-    BMX_EXP(BMX_TILE(1024, 76, 2, 5, 8)),        // 35: stamps, quad-SAD skip loop (last 8)
-    BMX_EXP(BMX_TILE(1024, 76, 2, 7, 0)),        // 36: variant 29 with s_setprio 3 around the DMA issue
-    BMX_EXP(BMX_TILE(1024, 76, 2, 8, 0)),        // 37: variant 29 + two clock stamps around the loop (in-kernel clock)
-    BMX_EXP(BMX_TILE(1024, 76, 2, 8, 7)),        // 38: variant 30 + clock stamps
-    BMX_EXP(BMX_TILE(1024, 76, 2, 8, 8)),        // 39: variant 31 + clock stamps
-    // split roles: |L| waves issue all of the DMA and walk a short share, the others only walk, a long one
-    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 0, 0, 8, 52)),   // 40: first 8 waves issue and walk 52 B/lane, last 8 walk 100
-    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 0, 0, -8, 52)),  // 41: the LAST 8 waves issue
-    BMX_EXP(BMX_TILE_LS(1024, 92, 2, 0, 0, 8, 60)),    // 42
-    BMX_EXP(BMX_TILE_LS(1024, 108, 2, 0, 0, 8, 44)),   // 43
-    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 7, 0, 8, 52)),   // 44: 40 with s_setprio 3 around the issue
-    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 7, 0, -8, 52)),  // 45: 41 with s_setprio
-    BMX_EXP(BMX_TILE_LS(1024, 92, 2, 0, 0, 4, 28)),    // 46: 4 issuers
-    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 0, 0, 12, 68)),  // 47: 12 issuers walk 68, 4 walk 100
-    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 5, 0, 8, 52)),   // 48: stamps of 40
-    BMX_EXP(BMX_TILE_LS(1024, 100, 2, 5, 0, -8, 52)),  // 49: stamps of 41
-    BMX_EXP(BMX_TILE(1024, 68, 2, 5, 3)),              // 50: stamps of 24 (4-gram walker)
-    BMX_EXP(BMX_TILE(1024, 68, 2, 8, 3)),              // 51: clock stamps of 24
-    BMX_EXP(BMX_TILE(1024, 76, 2, 0, 9)),              // 52: 76 KiB tiles, byte-wise walker behind the register bitmap (valid lists; slower)
-    BMX_TILE_S(1024, 76, 2, 10),                       // 53: PRODUCT -- 76 KiB tiles, 8-gram walker (m >= 8), static shares + a stolen tail
-    BMX_TILE_S(1024, 76, 2, 3),                        // 54: PRODUCT -- 76 KiB tiles, 4-gram walker, static shares + a stolen tail (ACGT, m = 8: +2 %)
-    BMX_EXP(BMX_TILE(1024, 76, 2, 5, 9)),              // 55: stamps of 52
-    BMX_EXP(BMX_TILE(1024, 76, 2, 5, 10)),             // 56: stamps of 53
-    BMX_EXP(BMX_RING_P(1024, 52, 2, 0, 1, 0)),         // 57: ring, DMA only, 3 x 52 KiB
-    BMX_EXP(BMX_RING_P(1024, 44, 2, 0, 1, 0)),         // 58: ring, DMA only, 3 x 44 KiB
-    BMX_EXP(BMX_RING_P(1024, 44, 2, 10, 0, 0)),        // 59: ring, 8-gram walker, 3 x 44 KiB
-    BMX_EXP(BMX_RING_P(1024, 44, 2, 0, 0, 0)),         // 60: ring, byte-wise walker, 3 x 44 KiB
-    BMX_EXP(BMX_RING_P(1024, 36, 2, 0, 1, 0)),         // 61: ring, DMA only, 3 x 36 KiB
-    BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 0, 0, 0, 1)),   // 62: variant 29, shares graded 108 / 92 / 60 / 44 by wave age
-    BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 0, 0, 0, 2)),   // 63: 100 / 84 / 68 / 52
-    BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 0, 0, 0, 3)),   // 64: 92 / 84 / 68 / 60
-    BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 0, 0, 0, 4)),   // 65: 44 / 60 / 92 / 108 (control: the wrong way round)
-    BMX_EXP(BMX_TILE_G(1024, 76, 2, 5, 0, 0, 0, 1)),   // 66: stamps of 62
-    BMX_EXP(BMX_TILE_G(1024, 76, 2, 0, 10, 0, 0, 2)),  // 67: 8-gram walker, graded 100 / 84 / 68 / 52
-    // DMA only with other cache-policy bits of global_load_lds (aux: 1 = sc0, 2 = nt, 16 = sc1)
-    BMX_EXP(BMX_TILE(1024, 76, 0, 1, 0)),              // 68
-    BMX_EXP(BMX_TILE(1024, 76, 1, 1, 0)),              // 69
-    BMX_EXP(BMX_TILE(1024, 76, 3, 1, 0)),              // 70
-    BMX_EXP(BMX_TILE(1024, 76, 16, 1, 0)),             // 71
-    BMX_EXP(BMX_TILE(1024, 76, 17, 1, 0)),             // 72
-    BMX_EXP(BMX_TILE(1024, 76, 18, 1, 0)),             // 73
-    BMX_EXP(BMX_TILE(1024, 76, 19, 1, 0)),             // 74
-    BMX_EXP(BMX_TILE(1024, 76, 3, 0, 0)),              // 75: variant 29 with sc0 nt
-    BMX_EXP(BMX_TILE(1024, 76, 18, 0, 0)),             // 76: variant 29 with sc1 nt
-    BMX_EXP(BMX_TILE(1024, 76, 2, 11, 0)),             // 77: variant 29, every workgroup a contiguous run of tiles
-    BMX_EXP(BMX_TILE(1024, 76, 2, 11, 10)),            // 78: variant 53 (8-gram walker) likewise
-    BMX_TILE_S(1024, 76, 2, 0),                        // 79: PRODUCT -- variant 29 with a stolen tail (scan_kernel MODE 12): long patterns on large alphabets
-    BMX_EXP(BMX_TILE_F(1024, 76, 2, 10)),              // 80: variant 53 without its stolen tail (static shares only)
-    BMX_EXP(BMX_TILE_F(1024, 76, 2, 3)),               // 81: variant 54 (4-gram walker) without its stolen tail
-    BMX_TILE_W32(1024, 36, 2, 12, 2),                  // 82: PRODUCT -- variant 2 (skip loop, two workgroups per CU) with a stolen tail: large alphabets, m = 9..12
-    BMX_EXP(BMX_TILE_FM(1024, 68, 2, 5, 0)),           // 83: variant 0 with stamps per tile phase, fill pass and per-tile counts as in the product (short patterns: m < 4)
-    BMX_EXP(BMX_TILE_FM(1024, 76, 2, 5, 0)),           // 84: variant 29 likewise
-    BMX_EXP(BMX_TILE_FM(1024, 68, 2, 8, 0)),           // 85: variant 0 with the two clock stamps only
-    BMX_EXP(BMX_TILE_FM(1024, 76, 2, 8, 0)),           // 86: variant 29 likewise
-    BMX_EXP(BMX_TILE_S(1024, 76, 2, 7)),               // 87: variant 30 (quad-SAD skip loop, last 4 bytes; m < 4: the whole pattern) with a stolen tail
-    BMX_EXP(BMX_TILE_S(1024, 76, 2, 8)),               // 88: variant 31 (last 8 bytes, m >= 8) with a stolen tail
+constexpr int N_VARIANTS = 89; // slots of the kernel table (built into this library or not)
+struct VariantTable {
+    Variant v[N_VARIANTS];
+    VariantTable()
+    {
+        for (Variant &x : v) x = Variant BMX_ABSENT;
+#define SLOT(I, ...) v[I] = Variant __VA_ARGS__
+#include "bmx_variants_product.inc"
+#ifdef BMX_EXPERIMENTS
+#include "bmx_variants_exp.inc"
+#endif
+#undef SLOT
+    }
 };
-constexpr int N_VARIANTS = sizeof(g_variants) / sizeof(g_variants[0]);
+const VariantTable g_table;
+const Variant *const g_variants = g_table.v;
+
 constexpr uint32_t LDS_PER_CU = 160 * 1024;
 
 } // namespace
@@ -318,13 +230,13 @@ uint64_t unit_bytes(const Variant &v)
     return v.kind != 1 ? 64ull * (uint64_t)(nl * v.segi + (v.block / 64 - nl) * v.seg) : 64ull * v.seg;
 }
 
-// LDS of one workgroup with two buffers of `cap` parked matches (bmx_scan_common.h report_hit).
+// LDS of one workgroup with two buffers of `cap` parked matches of 8 bytes (bmx_scan_common.h report_hit).
 uint32_t lds_bytes_with(const Variant &v, int32_t m, uint32_t cap)
 {
     const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
     const uint32_t waves = (uint32_t)v.block / 64u;
     const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u) + 256 +
-                            (v.qgram ? bmx::QGRAM_TABLE : 0u) + 128u + (cap ? 2u * cap * 4u + 32u : 0u);
+                            (v.qgram ? bmx::QGRAM_TABLE : 0u) + 128u + (cap ? 2u * cap * 8u + 32u : 0u);
     if (v.kind != 1) return (uint32_t)v.nbuf * ((uint32_t)unit_bytes(v) + halo16) + tables;
     return waves * v.nbuf * (64u * v.seg + halo16) + tables;
 }
@@ -336,7 +248,7 @@ uint32_t stage_cap_for(const Variant &v, int32_t m)
     if (v.kind != 0) return 0;
     const uint32_t bare = lds_bytes_with(v, m, 0);
     if (bare > LDS_PER_CU) return 0;
-    for (uint32_t cap = 2048; cap >= 128; cap /= 2) {
+    for (uint32_t cap = 1024; cap >= 64; cap /= 2) {
         const uint32_t with = lds_bytes_with(v, m, cap);
         if (with <= LDS_PER_CU && LDS_PER_CU / with == LDS_PER_CU / bare) return cap;
     }
@@ -366,6 +278,7 @@ constexpr int VARIANT_QGRAM4 = 54;   // 4-gram walker, 76 KiB tiles
 constexpr int VARIANT_QGRAM8 = 53;   // 8-gram walker, 76 KiB tiles
 constexpr int VARIANT_SKIP_STEAL = 82;     // skip loop on 36 KiB tiles, two workgroups per CU, static shares + a stolen tail
 constexpr int VARIANT_BIG_TILE_STEAL = 79; // ... with a stolen tail: the shorter the walk, the more a launch waits for its slowest workgroup
+constexpr int VARIANT_SAD = 87;      // quad-SAD skip loop on the last 4 pattern bytes, 76 KiB tiles, stolen tail
 constexpr int VARIANT_BIG_TILE = 29; // 76 KiB tiles: +2 % on large alphabets, but room for 512 parked matches per tile only
 
 // `canonical`: the shift tables in use are the ones bmx_build_tables makes (always so when the caller
@@ -419,9 +332,27 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
         if (v.canon_minm == 1) *use_short_kernel = false; // the quad-SAD skip loop takes any m
         return lds_bytes_for(v, m) <= LDS_PER_CU ? ctx->variant : 0; // buffers + halo do not fit at this m -> default
     }
-    if (is_short) return *sparse && fits(VARIANT_BIG_TILE) ? VARIANT_BIG_TILE : 0;
-    const bool large_alphabet = sigma > 0 ? sigma > 8 : distinct > 8;
+    // Whether the text's alphabet is large is only known from the second search on a text on (text_sigma); until then the
+    // pattern's own symbols have to do, and a word of five or more distinct letters is taken for text over a large alphabet
+    // (DNA and binary patterns have at most four; round 2 asked for more than eight and sent every short English word to
+    // the q-gram walkers on its first search).
+    const bool large_alphabet = sigma > 0 ? sigma > 8 : distinct > 4;
+    if (is_short) {
+        // m = 3, 4 with rare matches: the quad-SAD skip loop (4 GiB printable text, steady protocol, ms: m = 3: 0.62 against
+        // 0.75 for the short-pattern kernel, m = 4: 0.61 against 0.72); m = 2 (one position in 9,000): its stops cost it
+        // more than the short-pattern kernel's any-match filter (1.30 against 1.15); m = 1 and dense results: 68 KiB tiles
+        if (*sparse && canonical && m >= 3 && sigma > 8 && fits(VARIANT_SAD)) {
+            *use_short_kernel = false;
+            return VARIANT_SAD;
+        }
+        return *sparse && fits(VARIANT_BIG_TILE) ? VARIANT_BIG_TILE : 0;
+    }
     if (large_alphabet) { // sparse by nature (9^-4 and less)
+        // The quad-SAD skip loop (walk_lane_sad): no dependent LDS chain, ~1,500 cycles of walk per tile whatever m is, and
+        // with the parking ledger its matches cost it nothing in the loop: 4 GiB printable text, steady protocol, one match
+        // per MiB, ms: m = 16: 0.620 against 0.645-0.660 byte-wise (bench.py: 0.622 against 0.651), m = 64: 0.620 against
+        // 0.646, m = 4..12: 0.605-0.61 against 0.63-0.93 for the skip loop on 36 KiB tiles.  It needs the canonical tables.
+        if (canonical && fits(VARIANT_SAD)) return VARIANT_SAD;
         // short patterns: long walks, 32 waves per CU hide them better (4 GiB printable text, ms, byte-wise 76 KiB / skip loop
         // 36 KiB / the latter with a stolen tail: m = 8: - / 0.742 / 0.750, m = 10: 0.768 / 0.726 / 0.690, m = 12: 0.727 / 0.752 /
         // 0.697, m = 13: 0.703 / 0.775 / 0.714, m = 15: 0.685 / 0.766 / 0.715)
@@ -607,6 +538,7 @@ int bmx_scan_geometry(bmx_ctx *ctx, int32_t m, uint64_t out[6])
 }
 
 int bmx_last_search_sorted(bmx_ctx *ctx) { return ctx && ctx->last_sorted ? 1 : 0; }
+int bmx_last_variant(bmx_ctx *ctx) { return ctx ? ctx->last_variant : -1; }
 
 int bmx_stream_wait_last_scan(bmx_ctx *ctx, void *stream_v)
 {
@@ -849,7 +781,7 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
         a.tile_count = ctx->d_tile_count;
         a.dense_enabled = 0;
         // (m = 1..3: 1 KiB per wave in the parking area's place, where the fill pass lays a round's matches out in slot order)
-        const uint32_t lds = lds_bytes_with(v, ctx->last_m, ctx->last_short ? (v.seg > 68 ? 512u : 2048u) : 0u); // (ShortTile::BATCH x 4)
+        const uint32_t lds = lds_bytes_with(v, ctx->last_m, ctx->last_short ? (v.seg > 68 ? 256u : 1024u) : 0u); // (ShortTile::BATCH x 4)
         HIPCHK(hipFuncSetAttribute((const void *)fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (!ctx->last_counted) { // (the short-pattern kernel has left the counts already)
             a.wave_count = ctx->d_wave_count;
@@ -990,7 +922,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     {   // (the tables of long patterns can leave no room for the shift tables beside two 52 KiB tiles: byte-wise then)
         const uint32_t halo = ((uint32_t)(m_max - 1) + 15u) & ~15u;
         const uint32_t need = 2u * ((uint32_t)unit_bytes(g_multi_variant_q) + halo) + (uint32_t)blob.size() + q_bytes + 512 +
-                              ((((uint32_t)m_max + 7u) & ~7u) * 2) + (((uint32_t)m_max + 15u) & ~15u) + 256 + 128 + 2 * 128 * 4 + 32;
+                              ((((uint32_t)m_max + 7u) & ~7u) * 2) + (((uint32_t)m_max + 15u) & ~15u) + 256 + 128 + 2 * 64 * 8 + 32;
         if (need > LDS_PER_CU) qmask = 0;
     }
     const bool with_q = qmask != 0;
@@ -1035,9 +967,9 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     const uint32_t lds_fixed = 2u * ((uint32_t)tile + a.halo16) + a.multi_bytes + (with_q ? q_bytes : 0u) + 512 + ((((uint32_t)m_max + 7u) & ~7u) * 2) +
                                (((uint32_t)m_max + 15u) & ~15u) + 256 + 128;
     a.stage_cap = 0;
-    for (uint32_t cap = 1024; cap >= 128 && a.stage_cap == 0; cap /= 2)
-        if (lds_fixed + 2 * cap * 4 + 32 <= LDS_PER_CU) a.stage_cap = cap;
-    const uint32_t lds = lds_fixed + (a.stage_cap ? 2 * a.stage_cap * 4 + 32 : 0);
+    for (uint32_t cap = 512; cap >= 64 && a.stage_cap == 0; cap /= 2)
+        if (lds_fixed + 2 * cap * 8 + 32 <= LDS_PER_CU) a.stage_cap = cap;
+    const uint32_t lds = lds_fixed + (a.stage_cap ? 2 * a.stage_cap * 8 + 32 : 0);
     if (lds > LDS_PER_CU) {
         ctx->armed = true;
         return one_by_one();

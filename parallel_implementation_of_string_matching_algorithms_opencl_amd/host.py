@@ -89,6 +89,7 @@ SYMBOLS = [
     ("bmx_scan_geometry", C.c_int, [C.c_void_p, C.c_int32, _u64p]),
     ("bmx_set_variant", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("bmx_variant_count", C.c_int, []),
+    ("bmx_last_variant", C.c_int, [C.c_void_p]),
     ("bmx_edit_distance", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]),
     ("bmx_edit_distance_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
                                            C.c_void_p]),
@@ -403,6 +404,10 @@ class Context:
     def last_search_sorted(self) -> bool:
         """Did the last finish() have to sort (the list was unordered until then)?"""
         return bool(self._L.bmx_last_search_sorted(self._h))
+
+    def last_variant(self) -> int:
+        """The slot of the kernel table the most recent search ran."""
+        return int(self._L.bmx_last_variant(self._h))
 
     def set_variant(self, variant: int, blocks_per_cu: int = 0):
         self._chk(self._L.bmx_set_variant(self._h, variant, blocks_per_cu), "bmx_set_variant")

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 # bmx_shim.hip: the slots built into libbmx.so.  Every other slot (losing schedules, timing-only kernels whose
 # match lists are not valid) exists in libbmx_exp.so only and is refused by bmx_set_variant here.
-PRODUCT_VARIANTS = [0, 1, 2, 24, 25, 29, 53, 54, 79, 82]
+PRODUCT_VARIANTS = [0, 1, 2, 24, 25, 29, 53, 54, 79, 82, 87]
 QGRAM_VARIANTS = [24, 25, 53, 54]  # 4-gram and 8-gram walkers
 
 
@@ -488,7 +488,7 @@ def test_cpp_driver_on_a_reference_corpus_file(ctx, tmp_path):
     assert "occurrences: 1098" in r.stdout
     assert "Found at : 37" in r.stdout
     assert "Average time" in r.stdout and "process 1 is" in r.stdout
-    assert "1 GPUs, host buffers in and out: 1098 occurrences" in r.stdout and "identical to" in r.stdout
+    assert "1 GPUs, host buffers in and out: 1098 occurrences" in r.stdout and "identical to" in r.stdout and "DIFFERS" not in r.stdout
 
 
 def test_cpp_driver_second_and_third_program(ctx, port, tmp_path):
@@ -534,10 +534,10 @@ def test_dense_results_short_patterns(ctx, port):
 
 
 def test_walker_follows_the_texts_alphabet(built, port):
-    """Which walker runs is decided by the pattern AND by the alphabet of the text (four 4 KiB samples, looked at once
-    per text): a nine-letter word with few distinct letters is a small-alphabet pattern on DNA (8-gram rule, 76 KiB
-    tiles) and an ordinary word on English-like text (skip loop, 36 KiB tiles, two workgroups per CU -- the 8-gram
-    rule ran there at 2.6 TB/s instead of 6.0).  The lists are the oracle's either way."""
+    """Which walker runs is decided by the pattern AND by the alphabet of the text (sampled by the ordering kernel of
+    every search, known from the second search on a text on): a nine-letter word with few distinct letters is a
+    small-alphabet pattern on DNA (8-gram rule) and an ordinary word on English-like text (quad-SAD skip loop -- round 2's
+    8-gram rule ran there at 2.6 TB/s).  The lists are the oracle's either way."""
     import torch
 
     from parallel_implementation_of_string_matching_algorithms_opencl_amd import host
@@ -546,13 +546,13 @@ def test_walker_follows_the_texts_alphabet(built, port):
     n = 3_000_000
     english = (rng.integers(0, 60, n) + 60).astype(np.uint8)
     dna = (rng.integers(0, 4, n) + 65).astype(np.uint8)
-    out = torch.empty(1 << 16, dtype=torch.int64, device="cuda")
+    out = torch.empty(1 << 20, dtype=torch.int64, device="cuda")
     with host.Context(0) as c:
-        for text, tiles in ((english, {9: 36864, 6: 36864, 16: 77824}), (dna, {9: 77824, 6: 77824, 16: 77824})):
+        for text, slots in ((english, {9: 87, 6: 87, 16: 87, 3: 87, 2: 29}), (dna, {9: 53, 6: 54, 16: 53, 3: 0, 2: 0})):
             pats = {}
-            for m in tiles:
+            for m in slots:
                 pat = text[1000:1000 + m].tobytes()
-                if text is english:  # few distinct letters: "abcabcabc..."
+                if text is english and m > 4:  # few distinct letters: "abcabcabc..."
                     pat = (pat[:3] * 6)[:m]
                     text[5000 * m:5000 * m + m] = np.frombuffer(pat, dtype=np.uint8)
                 pats[m] = pat
@@ -562,16 +562,16 @@ def test_walker_follows_the_texts_alphabet(built, port):
             d = torch.from_numpy(text).cuda()
             pos, total = c.search_device(d, pats[16], out=out)
             assert np.array_equal(pos.cpu().numpy().astype(np.uint64), port.search(text, pats[16]))
-            for m, tile_bytes in tiles.items():
+            for m, slot in slots.items():
                 pat = pats[m]
                 pos, total = c.search_device(d, bytes(pat), out=out)
                 want = port.search(text, bytes(pat))
-                assert total == want.size and np.array_equal(pos.cpu().numpy().astype(np.uint64), want), (m, tile_bytes)
-                assert c.geometry(m)["tile_bytes"] == tile_bytes, (m, c.geometry(m))
+                assert total == want.size and np.array_equal(pos.cpu().numpy().astype(np.uint64), want), (m, slot)
+                assert c.last_variant() == slot, (m, slot, c.last_variant())
 
 
 def test_stolen_tail_on_small_texts(built, port):
-    """The kernels that hand their last tiles out by ticket (variants 53, 54, 79, 82) only do so when a workgroup has
+    """The kernels that hand their last tiles out by ticket (variants 53, 54, 79, 82, 87) only do so when a workgroup has
     two dozen tiles and more -- half a GiB of text on 256 CUs, which only the full-size tests reach.  With the grid
     capped at a few workgroups (the `max_grid` switch of libbmx_exp.so: same sources, same kernels) texts of a few MiB go through the pool: sparse, clustered
     and dense results, a misaligned pointer, shard semantics, a tile count that is no multiple of anything, and twice
@@ -585,7 +585,8 @@ def test_stolen_tail_on_small_texts(built, port):
     for grid in (3, 5):
         with host.Context(0, library=host.exp_lib()) as c:
             c.set_knob("max_grid", grid)
-            for variant, alpha, m in ((53, 4, 24), (53, 2, 64), (54, 4, 7), (79, 60, 40), (79, 4, 30), (82, 60, 10), (82, 60, 12)):
+            for variant, alpha, m in ((53, 4, 24), (53, 2, 64), (54, 4, 7), (79, 60, 40), (79, 4, 30), (82, 60, 10), (82, 60, 12), (87, 60, 16),
+                                     (87, 60, 5), (87, 60, 3), (87, 4, 20)):
                 n = int(rng.integers(9_000_000, 12_000_000))
                 text = (rng.integers(0, alpha, n) + 65).astype(np.uint8)
                 pat = text[12345:12345 + m].copy()
