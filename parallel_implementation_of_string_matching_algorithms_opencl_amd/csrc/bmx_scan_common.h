@@ -149,6 +149,7 @@ struct LdsTables {
     uint32_t stage_cap;   // entries per buffer
     uint32_t pat_id;      // which pattern of a multi-pattern pass these tables belong to (else 0): bits 20.. of a parked entry
     lds_u32 *wsum;        // 32 words: per-wave totals of the workgroup scans (count-only mode, fill pass)
+    lds_u32 *wcnt;        // 2 x 16 words: short patterns, the waves' match counts of the tile walked last / being walked
     // where a walker's matches go: 0 = the parking buffer (the scan), 1 = nowhere, this lane only counts them
     // (a workgroup that met a dense tile; first half of the fill pass), 2 = out[write_at++] (second half of the fill pass)
     uint32_t sink;
@@ -645,6 +646,7 @@ __device__ __forceinline__ uint32_t park_tile_short(const ScanArgs &a, const Lds
 {
     ShortTile<BLOCK, TILE> st;
     const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane, (a.dense_enabled & 2u) != 0);
+    if (__ballot(cnt != 0) == 0) return 0; // (wave-uniform) the usual case on a large alphabet: nothing to scan, nothing to park
     const uint32_t incl = wave_inclusive_scan(cnt);
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
     if (total == 0) return 0; // (wave-uniform)
@@ -964,7 +966,8 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
         end = s_q8 + QGRAM_TABLE;
     }
     tb.wsum = (lds_u32 *)to_lds(end);
-    end += 128;
+    tb.wcnt = tb.wsum + 32;
+    end += 256;
     tb.sink = 0;
     tb.pat_id = 0;
     tb.lane_cnt = 0;

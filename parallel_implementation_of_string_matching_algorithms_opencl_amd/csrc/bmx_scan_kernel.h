@@ -170,7 +170,12 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             const uint32_t lane16 = lane << 4;
             uint32_t c0 = first;
             for (; c0 + 64 <= nchunk; c0 += ISSUERS) dma16<AUX>(gsrc + ((uint64_t)c0 << 4) + lane16, dst + ((uint64_t)c0 << 4));
-            if (c0 < nchunk && c0 + lane < nchunk) dma16<AUX>(gsrc + ((uint64_t)c0 << 4) + lane16, dst + ((uint64_t)c0 << 4));
+            // The rest -- the halo: one chunk for m <= 17 -- is one more instruction for ONE wave.  In stride order it falls to
+            // wave 12 of 16 on 76 KiB tiles, one of the four waves whose instructions are accepted last anyway, and costs it
+            // 500-1,700 cycles more (stamps): the wave that gets its instructions accepted FIRST takes it instead.
+            constexpr uint32_t HALO_WAVE = NL ? 0u : 1u;
+            const uint32_t cr = nchunk & ~63u;
+            if ((NL ? iwave : wave) == HALO_WAVE && cr + lane < nchunk) dma16<AUX>(gsrc + ((uint64_t)cr << 4) + lane16, dst + ((uint64_t)cr << 4));
         } else {
             for (uint32_t c0 = first; c0 < nchunk; c0 += ISSUERS) {
                 const uint32_t c = c0 + lane;
@@ -235,7 +240,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         steal_begin = reserve >= 2 ? a.tile_begin + (per_wg - reserve) * gridDim.x : a.tile_end;
     }
     uint32_t it = 0; // tiles walked so far by this workgroup
-    uint32_t short_wc = 0; // WALK 6: matches this wave counted in the tile it walked last (wave-uniform)
     // The parking ledger.  Matches are parked in the ACTIVE one of two LDS buffers -- not tile by tile, as round 2 did, but
     // for as many tiles as it takes to half-fill it -- and a buffer is emptied into HBM (ONE global atomic reserves its
     // slots, then the workgroup stores) a tile period after it stopped being the active one.  With one match per MiB (the
@@ -323,13 +327,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             }
         }
         if (issue_now && !issue_late) issue_tile(tn, cur ? buf0 : buf1);
-        // Short patterns: what this wave counted in the PREVIOUS tile goes to HBM now (the fill pass of a dense result starts
-        // from these counts).  Stored right behind the walk -- as round 2 did -- the store is the youngest entry of vmcnt when
-        // the wave reaches the period's top, and the wait for the tile DMA there also waits for the store's acknowledgement:
-        // a write round trip on the critical path of every tile.  Issued here it has the whole walk to complete.
+        // Short patterns: what the waves counted in the PREVIOUS tile goes to HBM now (the fill pass of a dense result starts
+        // from these counts): ONE store instruction of wave 0 for the workgroup, out of LDS.  Round 2 had every wave store its
+        // own count right behind its walk: the store was the youngest entry of vmcnt when the wave reached the period's top,
+        // and the wait for the tile DMA there also waited for the store's acknowledgement; and sixteen more vector-memory
+        // instructions per tile queue up with the five DMA instructions a wave has to get accepted (stamps: ~800 cycles
+        // of the issue phase).
         if constexpr (WALK == 6 && SCAN_MODE)
-            if (a.wave_count != nullptr && it != 0 && lane == 0)
-                a.wave_count[((ST ? t_prev : t - t_step) - a.tile_begin) * (uint64_t)NW + wave] = short_wc;
+            if (a.wave_count != nullptr && it != 0 && wave == 0 && lane < (uint32_t)NW)
+                a.wave_count[((ST ? t_prev : t - t_step) - a.tile_begin) * (uint64_t)NW + lane] = tb.wcnt[((it & 1u) ^ 1u) * 16u + lane];
         // The ledger's bookkeeping for the PREVIOUS tile (one LDS word, requested above): its match count, and whether
         // the active buffer is due.  Nothing here touches global memory unless a buffer goes out.
         uint32_t fl_n = 0, fl_buf = 0; // a buffer on its way out in THIS period: entries, which one
@@ -489,7 +495,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             if constexpr (WALK == 6 && SCAN_MODE && LOADERS == 0 && GRADE == 0) {
                 if (tb.stage_cap != 0) { // m = 1..3: sixteen window starts per 128-bit read, one LDS atomic per wave and tile
                     const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
-                    short_wc = park_tile_short<BLOCK, TILE>(a, tb, T, lo_t, rem < (uint64_t)TILE ? (uint32_t)rem : TILE, tile_off, wave, lane, wg_dense);
+                    const uint32_t wc = park_tile_short<BLOCK, TILE>(a, tb, T, lo_t, rem < (uint64_t)TILE ? (uint32_t)rem : TILE, tile_off, wave, lane, wg_dense);
+                    if (a.wave_count != nullptr && lane == 0) tb.wcnt[(it & 1u) * 16u + wave] = wc;
                 } else {
                     walk_tile();
                 }
@@ -533,7 +540,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
         const uint32_t now = __builtin_amdgcn_readfirstlane(*park_cnt(ab & 1u));
         const uint32_t n_true = now - last_now;
         if constexpr (WALK == 6 && SCAN_MODE)
-            if (a.wave_count != nullptr && lane == 0) a.wave_count[((STEAL ? t_prev : t - t_step) - a.tile_begin) * (uint64_t)NW + wave] = short_wc;
+            if (a.wave_count != nullptr && wave == 0 && lane < (uint32_t)NW)
+                a.wave_count[((STEAL ? t_prev : t - t_step) - a.tile_begin) * (uint64_t)NW + lane] = tb.wcnt[((it & 1u) ^ 1u) * 16u + lane];
         if constexpr (WALK == 6 && SCAN_MODE)
             if (a.tile_count != nullptr && tid == 0) a.tile_count[(STEAL ? t_prev : t - t_step) - a.tile_begin] = n_true;
         const uint32_t fill = now - ep_act;

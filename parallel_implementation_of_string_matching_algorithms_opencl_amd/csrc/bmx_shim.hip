@@ -23,6 +23,7 @@
 
 #include "bmx_aux_kernels.h"
 #include "bmx_ed_band_kernel.h"
+#include "bmx_ed_bits_kernel.h"
 #include "bmx_ed_kernel.h"
 #ifdef BMX_EXPERIMENTS
 #include "bmx_scan_ring_kernel.h"
@@ -195,8 +196,8 @@ struct bmx_ctx {
     uint32_t *d_wave_count = nullptr;      // 1-3-byte patterns: matches per wave piece of every tile (block / 64 words per tile)
     uint64_t tile_cap = 0;                 // tiles both arrays have room for
     int multi_attr[2] = {0, 0};            // dynamic-LDS limit set for the two multi-pattern kernels on this device
-    uint8_t *d_multi = nullptr;            // bmx_search_device_multi: the patterns' tables (one blob) and first[]
-    uint64_t *d_multi_first = nullptr;
+    uint8_t *d_multi = nullptr;            // bmx_search_device_multi: the patterns' tables (one blob) in HBM ...
+    uint8_t *h_multi = nullptr;            // ... and the pinned host buffer they are copied from (truly asynchronous; no wait for a pageable copy)
     bmx::ScanArgs last_args;               // the last scan launch (the fill pass re-runs its geometry)
     int last_grid = 0;
     int32_t last_m = 0;
@@ -236,7 +237,7 @@ uint32_t lds_bytes_with(const Variant &v, int32_t m, uint32_t cap)
     const uint32_t halo16 = ((uint32_t)(m - 1) + 15u) & ~15u;
     const uint32_t waves = (uint32_t)v.block / 64u;
     const uint32_t tables = 256 * 2 + (((uint32_t)m + 7u) & ~7u) * 2 + (((uint32_t)m + 15u) & ~15u) + 256 +
-                            (v.qgram ? bmx::QGRAM_TABLE : 0u) + 128u + (cap ? 2u * cap * 8u + 32u : 0u);
+                            (v.qgram ? bmx::QGRAM_TABLE : 0u) + 256u + (cap ? 2u * cap * 8u + 32u : 0u);
     if (v.kind != 1) return (uint32_t)v.nbuf * ((uint32_t)unit_bytes(v) + halo16) + tables;
     return waves * v.nbuf * (64u * v.seg + halo16) + tables;
 }
@@ -337,22 +338,35 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
     // (DNA and binary patterns have at most four; round 2 asked for more than eight and sent every short English word to
     // the q-gram walkers on its first search).
     const bool large_alphabet = sigma > 0 ? sigma > 8 : distinct > 4;
+    // ... and is it spread like random text?  Prose shows ~45 distinct bytes in the sample, printable-95 text all 95.  On
+    // English-LIKE text (Zipf words over 27 symbols, tools/english_like.py) n-grams repeat, the quad-SAD skip loop stops where
+    // the text shows the pattern's last four bytes, and frequent short words cost it twice what they cost the others (1 GiB,
+    // ms, quad-SAD / skip loop on 36 KiB tiles / byte-wise: `esh` 0.62 / 0.43 / 0.31 (short-pattern kernel), ` esh ` 0.95 /
+    // 0.52 / 0.95, a word of 6: 0.32 / 0.29 / 0.41, of 8: 0.22 / 0.23 / 0.29, of 10 + blank: 0.25 / 0.29 / 0.42, a rare one
+    // of 12: 0.20 / 0.22 / 0.28): there it only takes over from m = 8
+    const bool uniform_like = sigma > 0 ? sigma > 64 : distinct > 4;
     if (is_short) {
         // m = 3, 4 with rare matches: the quad-SAD skip loop (4 GiB printable text, steady protocol, ms: m = 3: 0.62 against
         // 0.75 for the short-pattern kernel, m = 4: 0.61 against 0.72); m = 2 (one position in 9,000): its stops cost it
         // more than the short-pattern kernel's any-match filter (1.30 against 1.15); m = 1 and dense results: 68 KiB tiles
-        if (*sparse && canonical && m >= 3 && sigma > 8 && fits(VARIANT_SAD)) {
+        if (*sparse && canonical && m >= 3 && sigma > 64 && fits(VARIANT_SAD)) {
             *use_short_kernel = false;
             return VARIANT_SAD;
         }
-        return *sparse && fits(VARIANT_BIG_TILE) ? VARIANT_BIG_TILE : 0;
+        // everything else: the short-pattern kernel.  76 KiB tiles unless more than one position in eight matches (1 GiB,
+        // whole search incl. the fill pass, ms, 68 / 76 KiB tiles: printable text, m = 1: 0.83 / 0.71; ACGT, m = 2: 0.80 /
+        // 0.75, m = 3: 0.83 / 0.69, m = 4: 0.76 / 0.70; but ACGT, m = 1 -- 268 M matches -- 1.02 / 1.31: the fill pass of the
+        // smaller tiles lays 512 matches out per turn, that of the larger ones 128)
+        double density = 1.0;
+        for (int i = 0; i < m; ++i) density /= (double)(sigma > 0 ? sigma : distinct);
+        return density <= 0.125 && fits(VARIANT_BIG_TILE) ? VARIANT_BIG_TILE : 0;
     }
     if (large_alphabet) { // sparse by nature (9^-4 and less)
         // The quad-SAD skip loop (walk_lane_sad): no dependent LDS chain, ~1,500 cycles of walk per tile whatever m is, and
         // with the parking ledger its matches cost it nothing in the loop: 4 GiB printable text, steady protocol, one match
         // per MiB, ms: m = 16: 0.620 against 0.645-0.660 byte-wise (bench.py: 0.622 against 0.651), m = 64: 0.620 against
         // 0.646, m = 4..12: 0.605-0.61 against 0.63-0.93 for the skip loop on 36 KiB tiles.  It needs the canonical tables.
-        if (canonical && fits(VARIANT_SAD)) return VARIANT_SAD;
+        if (canonical && (uniform_like || m >= 8) && fits(VARIANT_SAD)) return VARIANT_SAD;
         // short patterns: long walks, 32 waves per CU hide them better (4 GiB printable text, ms, byte-wise 76 KiB / skip loop
         // 36 KiB / the latter with a stolen tail: m = 8: - / 0.742 / 0.750, m = 10: 0.768 / 0.726 / 0.690, m = 12: 0.727 / 0.752 /
         // 0.697, m = 13: 0.703 / 0.775 / 0.714, m = 15: 0.685 / 0.766 / 0.715)
@@ -459,9 +473,10 @@ int bmx_ctx_create(int device, bmx_ctx **out)
         e = hipMalloc(&ctx->d_bucket_store, (size_t)bmx::ORDER_BUCKETS * bmx::ORDER_BUCKET_CAP * sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc(&ctx->d_overflow, 8 * sizeof(uint32_t)); // {bucket overflow, scan error, dense, ticket counter, tiles walked (stolen-tail kernels), -, -, -}
     if (e == hipSuccess) e = hipMalloc(&ctx->d_status, 4 * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 8 * sizeof(uint64_t), hipHostMallocMapped); // [4], [5]: alphabet sample {sigma, seq}; [6]: order_kernel's sample
+    // [0..3] {count, needs_sort, seq, scan error}; [6]: order_kernel's text sample; [8..16]: where each pattern's list begins (multi-pattern pass)
+    if (e == hipSuccess) e = hipHostMalloc(&ctx->h_status, 32 * sizeof(uint64_t), hipHostMallocMapped);
     if (e == hipSuccess) {
-        std::memset(ctx->h_status, 0, 8 * sizeof(uint64_t));
+        std::memset(ctx->h_status, 0, 32 * sizeof(uint64_t));
         e = hipHostGetDevicePointer((void **)&ctx->h_status_dev, ctx->h_status, 0);
     }
     for (int i = 0; i < bmx_ctx::EV_RING && e == hipSuccess; ++i) {
@@ -483,7 +498,7 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->d_count) (void)hipFree(ctx->d_count);
     if (ctx->d_multi) (void)hipFree(ctx->d_multi);
-    if (ctx->d_multi_first) (void)hipFree(ctx->d_multi_first);
+    if (ctx->h_multi) (void)hipHostFree(ctx->h_multi);
     if (ctx->d_tile_count) (void)hipFree(ctx->d_tile_count);
     if (ctx->d_tile_base) (void)hipFree(ctx->d_tile_base);
     if (ctx->d_wave_count) (void)hipFree(ctx->d_wave_count);
@@ -826,10 +841,11 @@ int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_o
 // ---- several patterns in one pass ----------------------------------------
 namespace {
 constexpr uint32_t MULTI_BLOB_MAX = bmx::MAX_MULTI * (512 + 2 * ((BMX_MAX_PATTERN + 7) & ~7) + BMX_MAX_PATTERN + 32);
-const auto g_multi_kernel = bmx::scan_kernel<1024, 68, 2, 0, 20>;
+// (static tile shares + a stolen tail, scan_kernel MODE 12, like the single-pattern kernels: round 3)
+const auto g_multi_kernel = bmx::scan_kernel<1024, 68, 2, 12, 20>;
 const Variant g_multi_variant = {0, 1024, 68, 2, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 // the same pass with the 8-gram rule for the patterns over small alphabets (one 4 KiB shift table each in LDS: 52 KiB tiles)
-const auto g_multi_kernel_q = bmx::scan_kernel<1024, 52, 2, 0, 21>;
+const auto g_multi_kernel_q = bmx::scan_kernel<1024, 52, 2, 12, 21>;
 const Variant g_multi_variant_q = {0, 1024, 52, 2, 0, 0, false, false, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 } // namespace
 
@@ -901,10 +917,11 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     for (int k = K; k < BMX_MAX_MULTI; ++k) a.multi_off[k] = a.multi_m[k] = 0, a.multi_own_end[k] = 0;
     if (n_starts_max == 0) return BMX_OK;
     if (!ctx->d_multi) HIPCHK(hipMalloc(&ctx->d_multi, MULTI_BLOB_MAX));
-    constexpr size_t first_bytes = (bmx::MAX_MULTI + 1) * sizeof(uint64_t);
-    if (!ctx->d_multi_first) HIPCHK(hipMalloc(&ctx->d_multi_first, first_bytes));
-    HIPCHK(hipMemcpyAsync(ctx->d_multi, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipStreamSynchronize(stream)); // (the blob is a local)
+    if (!ctx->h_multi) HIPCHK(hipHostMalloc(&ctx->h_multi, MULTI_BLOB_MAX, hipHostMallocDefault));
+    // (through pinned memory the copy is asynchronous and nothing waits for it here; the buffer is free again when this call
+    // returns -- it ends with the wait for the search's status word, which the kernels behind the copy write)
+    std::memcpy(ctx->h_multi, blob.data(), blob.size());
+    HIPCHK(hipMemcpyAsync(ctx->d_multi, ctx->h_multi, blob.size(), hipMemcpyHostToDevice, stream));
 
     ctx->timed = false;
     if (!ctx->armed) {
@@ -922,7 +939,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     {   // (the tables of long patterns can leave no room for the shift tables beside two 52 KiB tiles: byte-wise then)
         const uint32_t halo = ((uint32_t)(m_max - 1) + 15u) & ~15u;
         const uint32_t need = 2u * ((uint32_t)unit_bytes(g_multi_variant_q) + halo) + (uint32_t)blob.size() + q_bytes + 512 +
-                              ((((uint32_t)m_max + 7u) & ~7u) * 2) + (((uint32_t)m_max + 15u) & ~15u) + 256 + 128 + 2 * 64 * 8 + 32;
+                              ((((uint32_t)m_max + 7u) & ~7u) * 2) + (((uint32_t)m_max + 15u) & ~15u) + 256 + 256 + 2 * 64 * 8 + 32;
         if (need > LDS_PER_CU) qmask = 0;
     }
     const bool with_q = qmask != 0;
@@ -965,7 +982,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     a.bucket_shift = 0;
     while (((n_starts_max - 1) >> a.bucket_shift) >= (uint64_t)a.bucket_stride) ++a.bucket_shift;
     const uint32_t lds_fixed = 2u * ((uint32_t)tile + a.halo16) + a.multi_bytes + (with_q ? q_bytes : 0u) + 512 + ((((uint32_t)m_max + 7u) & ~7u) * 2) +
-                               (((uint32_t)m_max + 15u) & ~15u) + 256 + 128;
+                               (((uint32_t)m_max + 15u) & ~15u) + 256 + 256;
     a.stage_cap = 0;
     for (uint32_t cap = 512; cap >= 64 && a.stage_cap == 0; cap /= 2)
         if (lds_fixed + 2 * cap * 8 + 32 <= LDS_PER_CU) a.stage_cap = cap;
@@ -989,7 +1006,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     ctx->last_fillable = false;
     hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, d_match_positions, capacity, ctx->d_count,
                        ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status, ctx->h_status_dev, ++ctx->seq,
-                       ctx->d_multi_first, a.bucket_stride / 8u, (const uint8_t *)d_text, n, 0u);
+                       ctx->h_status_dev + 8, a.bucket_stride / 8u, (const uint8_t *)d_text, n, (uint32_t)(a.tile_end - a.tile_begin));
     ctx->last_text = d_text, ctx->last_text_n = n;
     HIPCHK(hipGetLastError());
     ctx->armed = true;
@@ -997,9 +1014,9 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     rc = bmx_search_device_finish(ctx, nullptr, 0, &total, stream); // waits for the status word; no list handling here
     if (rc != BMX_OK && rc != BMX_ERR_CAPACITY) return rc;
     if (ctx->h_status[1] != 0 || total > capacity) return one_by_one(); // unordered / dense / too many: the exact way
-    uint64_t h_first[BMX_MAX_MULTI + 1];
-    HIPCHK(hipMemcpyAsync(h_first, ctx->d_multi_first, kp2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipStreamSynchronize(stream));
+    // where each pattern's list begins: written by the ordering kernel into the pinned status block in front of the sequence
+    // number the wait above has seen (no copy, no stream synchronisation)
+    const uint64_t *h_first = ctx->h_status + 8;
     for (int k = 0; k < K; ++k) {
         first[k] = h_first[k];
         n_matches[k] = (k + 1 < (int)kp2 ? h_first[k + 1] : total) - h_first[k];
@@ -1045,7 +1062,10 @@ struct EdVariant {
     void (*dual)(const bmx::EdArgs);       // a forward and a mirrored tile diagonal per launch (nullptr: none)
     int band_c;                            // band pipeline: 64*band_c columns per wave
     void (*band)(const bmx::EdBandArgs);   // the whole table in one launch: pipeline of column bands, both directions
-    void (*band16)(const bmx::EdBandArgs); // same with 16-row hand-over groups (experiments: BMX_ED_GROUP=16)
+    void (*band16)(const bmx::EdBandArgs); // same with 16-row hand-over groups (libbmx_exp.so: knob ed_group)
+    uint32_t band_lds = 0;                 // dynamic LDS of the band kernel (the bit-parallel band's Eq table)
+    int band_lag = 180;                    // rows a band trails its predecessor by (measured; places the cut rows)
+    double step_cost = 0.0;                // instructions per row step, for the choice of the band (0: 25 + 3 band_c)
 };
 #define BMX_ED(C_, R_, BC_)                                                                                     \
     {C_, R_, bmx::ed_tile_kernel<C_, R_, true>, bmx::ed_dual_kernel<C_, R_>, BC_, bmx::ed_band_kernel<BC_, 32>, \
@@ -1060,6 +1080,9 @@ const EdVariant g_ed_variants[] = {
                                                                                 // shuffle, predicated steps)
     BMX_ED(4, 512, 7), // 6
     BMX_ED(3, 256, 3), // 7
+    // 8: the bit-parallel band (bmx_ed_bits_kernel.h): 2048 columns per wave, 32 per lane as two words of differences
+    {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits_kernel<32>, bmx::ed_bits_kernel<16>,
+     bmx::ED_BITS_LDS, 200, 34.0},
 };
 constexpr int N_ED_VARIANTS = sizeof(g_ed_variants) / sizeof(g_ed_variants[0]);
 constexpr int ED_ONE_DIRECTION = 16; // flag on the variant number: tiles, from the top-left corner only
@@ -1067,7 +1090,6 @@ constexpr int ED_TILES = 32;         // flag: tiles from both corners (one launc
 constexpr int ED_FLAGS = ED_ONE_DIRECTION | ED_TILES;
 constexpr uint64_t ED_BAND_WS_LIMIT = 16ull << 30; // bytes of right-column storage the band pipeline may take
 constexpr uint64_t ED_BAND_WS_KEEP = 1ull << 30;   // workspaces up to this size stay in the context between calls
-constexpr int ED_BAND_LAG = 180;                   // rows a band trails its predecessor by (measured; sets the cut rows)
 
 // Band pipeline (bmx_ed_band_kernel.h).  Returns BMX_OK with *used = false if it does not apply
 // (workspace too large / allocation refused): the caller then takes the tile schedule.
@@ -1115,7 +1137,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
         ctx->ed_ws_shape[1] = lb;
         ctx->ed_ws_shape[2] = W;
     }
-    const int lag = ctx->ed_lag_set ? ctx->ed_lag : ED_BAND_LAG;
+    const int lag = ctx->ed_lag_set ? ctx->ed_lag : v.band_lag;
     bmx::EdBandArgs a = {};
     a.a = (const uint8_t *)d_a;
     a.b = (const uint8_t *)d_b;
@@ -1143,8 +1165,12 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(ctx->ed_group == 16 ? v.band16 : v.band, dim3(2 * bands), dim3(64), 0, stream, a);
-        e = hipGetLastError();
+        const auto kern = ctx->ed_group == 16 ? v.band16 : v.band;
+        if (v.band_lds > 64 * 1024) e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.band_lds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(kern, dim3(2 * bands), dim3(64), v.band_lds, stream, a);
+            e = hipGetLastError();
+        }
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(bmx::ed_band_meet_kernel, dim3(bands), dim3(256), 0, stream, a, W, (int32_t *)d_result);
@@ -1207,7 +1233,7 @@ int bmx_edit_distance_device(bmx_ctx *ctx, const void *d_a, uint64_t la, const v
             for (const EdVariant &c : g_ed_variants) {
                 if (!c.band) continue;
                 const double bands = (double)((la + 64 * c.band_c - 1) / (64 * c.band_c));
-                const double t = ((double)lb / 2 + bands * ED_BAND_LAG / 2) * (25.0 + 3.0 * c.band_c);
+                const double t = ((double)lb / 2 + bands * c.band_lag / 2) * (c.step_cost > 0.0 ? c.step_cost : 25.0 + 3.0 * c.band_c);
                 if (best == 0.0 || t < best) {
                     best = t;
                     pick = &c;

@@ -546,13 +546,17 @@ def test_walker_follows_the_texts_alphabet(built, port):
     n = 3_000_000
     english = (rng.integers(0, 60, n) + 60).astype(np.uint8)
     dna = (rng.integers(0, 4, n) + 65).astype(np.uint8)
+    p95 = (rng.integers(0, 95, n) + 32).astype(np.uint8)
     out = torch.empty(1 << 20, dtype=torch.int64, device="cuda")
     with host.Context(0) as c:
-        for text, slots in ((english, {9: 87, 6: 87, 16: 87, 3: 87, 2: 29}), (dna, {9: 53, 6: 54, 16: 53, 3: 0, 2: 0})):
+        # (up to 64 distinct bytes in the sample: prose-like -- the quad-SAD skip loop from m = 8, the skip loop below, the
+        # short-pattern kernel up to m = 4; more: spread like random text -- quad-SAD from m = 3)
+        for text, slots in ((english, {9: 87, 6: 2, 16: 87, 3: 29, 2: 29}), (dna, {9: 53, 6: 54, 16: 53, 3: 29, 2: 29, 1: 0}),
+                            (p95, {9: 87, 6: 87, 16: 87, 4: 87, 3: 87, 2: 29, 1: 29})):
             pats = {}
             for m in slots:
                 pat = text[1000:1000 + m].tobytes()
-                if text is english and m > 4:  # few distinct letters: "abcabcabc..."
+                if text is not dna and m > 4:  # few distinct letters: "abcabcabc..."
                     pat = (pat[:3] * 6)[:m]
                     text[5000 * m:5000 * m + m] = np.frombuffer(pat, dtype=np.uint8)
                 pats[m] = pat

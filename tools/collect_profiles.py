@@ -75,7 +75,11 @@ def collect_dir(args, prof):
         if sq:
             tag = f"_{args.tag}" if args.tag else ""
             sq_summary(sq[-1], os.path.join(prof, f"{args.round}_sq_scan_kernel{tag}_{w}.csv"))
-    for extra in ("dma_only", "ed64k", "sa2m"):
+    sq = glob.glob(os.path.join(d, "sq_short_m2", "*", "*_counter_collection.csv"))
+    if sq:
+        tag = f"_{args.tag}" if args.tag else ""
+        sq_summary(sq[-1], os.path.join(prof, f"{args.round}_sq_scan_kernel{tag}_short_m2.csv"))
+    for extra in ("dma_only", "ed64k", "sa2m", "short"):
         st = glob.glob(os.path.join(d, f"stats_{extra}", "*", "*_kernel_stats.csv"))
         if st:
             tag = f"_{args.tag}" if args.tag else ""
