@@ -41,11 +41,16 @@ constexpr uint32_t ED_BITS_W = 2048;          // columns per band: 64 lanes x 32
 constexpr uint32_t ED_BITS_PEQ_STRIDE = 257;  // words between two lanes' rows of the Eq table (odd: bank spread)
 constexpr uint32_t ED_BITS_LDS = 64 * ED_BITS_PEQ_STRIDE * 4;
 
-template <int GROUP>
+// R rows per step.  A step of the one-row kernel is ~40 instructions of which 14 are the recurrence: the rest -- the two row
+// windows' rotation, the hand to the right neighbour, the collector of the band's right edge, the loop -- is paid per STEP, so
+// a lane that takes R consecutive rows of its 32 columns per step (the systolic skew becomes R rows per lane) pays it once
+// per R rows.  A window entry then holds R rows: R characters in one word, R difference codes of two bits.
+template <int GROUP, int R>
 __global__ __launch_bounds__(64) void ed_bits_kernel(const EdBandArgs a)
 {
+    static_assert(R >= 1 && R <= 4, "a window entry packs R characters into one word");
     constexpr uint32_t W = ED_BITS_W;
-    constexpr uint32_t G = GROUP;
+    constexpr uint32_t G = GROUP; // window entries per hand-over group (an entry = R rows)
     extern __shared__ uint32_t ed_peq[]; // [64][257]: ed_peq[l * 257 + c] = the columns of lane l whose character is c
 
     const uint32_t lane = threadIdx.x;
@@ -55,6 +60,7 @@ __global__ __launch_bounds__(64) void ed_bits_kernel(const EdBandArgs a)
     const uint32_t col0 = J * W;
     const uint32_t ncols = a.la - col0 < W ? a.la - col0 : W;
     const uint32_t nrows = mirror ? a.lb - a.cut[J] : a.cut[J];
+    const uint32_t nent = (nrows + R - 1) / R; // window entries = steps a lane takes
     auto phys_r = [&](uint32_t rr) { return mirror ? a.lb - rr : rr; };
     auto phys_c = [&](uint32_t cc) { return mirror ? col0 + ncols - cc : col0 + cc; };
 
@@ -78,20 +84,33 @@ __global__ __launch_bounds__(64) void ed_bits_kernel(const EdBandArgs a)
 
     const uint64_t t_start = wall_clock64();
     bool failed = false;
-    auto row_of = [&](uint32_t first) {
-        const uint32_t rr = first + (lane & (G - 1));
+    // row q of the entry this lane loads for the group that starts at entry `first` (clamped: a row past the end is never consumed)
+    auto row_of = [&](uint32_t first, uint32_t q) {
+        const uint32_t rr = (first + (lane & (G - 1))) * R + q;
         return rr < nrows ? rr : nrows - 1;
     };
-    auto load_left = [&](uint32_t first) {
-        return __hip_atomic_load(prev_rc + phys_r(row_of(first) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    struct Group {
+        uint64_t left[R];
+        uint8_t b[R];
     };
-    auto load_b = [&](uint32_t first) {
-        const uint32_t rr = row_of(first);
-        return a.b[mirror ? a.lb - 1 - rr : rr];
+    auto load_group = [&](uint32_t first) {
+        Group g;
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) {
+            const uint32_t rr = row_of(first, q);
+            g.left[q] = __hip_atomic_load(prev_rc + phys_r(rr + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g.b[q] = a.b[mirror ? a.lb - 1 - rr : rr];
+        }
+        return g;
     };
-    auto validate = [&](uint64_t e, uint32_t first) {
+    // wait until the group is valid (reloading what is not); returns its F values
+    auto validate = [&](Group &g, uint32_t first, uint32_t (&f)[R]) {
         uint32_t polls = 0;
-        while (__ballot((uint32_t)(e >> 32) != a.tag) != 0) {
+        for (;;) {
+            bool bad = false;
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q) bad = bad || (uint32_t)(g.left[q] >> 32) != a.tag;
+            if (__ballot(bad) == 0) break;
             if ((++polls & 31u) == 0 &&
                 (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                  wall_clock64() - t_start > a.timeout_ticks)) {
@@ -99,19 +118,33 @@ __global__ __launch_bounds__(64) void ed_bits_kernel(const EdBandArgs a)
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
-            e = load_left(first);
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q)
+                g.left[q] = __hip_atomic_load(prev_rc + phys_r(row_of(first, q) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        return (uint32_t)e;
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) f[q] = (uint32_t)g.left[q];
     };
-    // The edge's F values of a group of G rows (lane i and lane i + G hold row first + i) as row-to-row differences of D,
-    // two bits: bit 0 = +1, bit 1 = -1.  D[r] - D[r-1] = F[r] - F[r-1] + 1; `prev_f` = the F of the row in front of the group.
+    // The edge's F values of a group (lane i and lane i + G hold entry first + i) as row-to-row differences of D, two bits per
+    // row: bit 0 = +1, bit 1 = -1.  D[r] - D[r-1] = F[r] - F[r-1] + 1; `prev_f` = the F of the row in front of the group.
     uint32_t prev_f = 0u; // F at vertex (0, c0): the table's edge row
-    auto to_code = [&](uint32_t f) {
-        uint32_t up = __builtin_amdgcn_update_dpp(0, (int)f, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+    auto to_code = [&](const uint32_t (&f)[R]) {
+        uint32_t up = __builtin_amdgcn_update_dpp(0, (int)f[R - 1], 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
         up = (lane & (G - 1)) == 0 ? prev_f : up;
-        const int32_t d = (int32_t)f - (int32_t)up; // -2, -1, 0
-        prev_f = __builtin_amdgcn_readlane(f, G - 1);
-        return (uint32_t)(d == 0 ? 1u : 0u) | (d == -2 ? 2u : 0u);
+        prev_f = __builtin_amdgcn_readlane(f[R - 1], G - 1);
+        uint32_t code = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) {
+            const int32_t d = (int32_t)f[q] - (int32_t)(q == 0 ? up : f[q - 1]); // -2, -1, 0
+            code |= ((d == 0 ? 1u : 0u) | (d == -2 ? 2u : 0u)) << (2 * q);
+        }
+        return code;
+    };
+    auto pack_b = [&](const Group &g) {
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) w |= (uint32_t)g.b[q] << (8 * q);
+        return w;
     };
 
     // the band's right edge: bit out_bit of lane out_lane (bit 31 of lane 63 unless the band is the narrow last one)
@@ -120,90 +153,119 @@ __global__ __launch_bounds__(64) void ed_bits_kernel(const EdBandArgs a)
     const bool is_out = lane == out_lane;
     uint32_t Pv = ~0u, Mv = 0u; // row 0: D[0][c] = c
     uint32_t fe = 0u;           // F at my right edge (vertex column 32 (lane + 1), or the band's edge), current row
-    uint32_t last_h2 = 0u, bc = 0u;
-    uint32_t acc = 0;
-    uint32_t win_left = 0, win_b = 0; // the row windows: before step s, row s + l in lane l (l < 2G)
-    uint32_t eq_cur = 0u;
+    uint32_t last_codes = 0u, bcs = 0u;
+    uint32_t acc[R];
+#pragma unroll
+    for (uint32_t q = 0; q < R; ++q) acc[q] = 0;
+    uint32_t win_left = 0, win_b = 0; // the row windows: before step s, entry s + l in lane l (l < 2G)
+    uint32_t eq_cur[R];
+#pragma unroll
+    for (uint32_t q = 0; q < R; ++q) eq_cur[q] = 0u;
     const uint32_t peq_base = (uint32_t)(uintptr_t)my_peq; // (LDS byte address of my row)
 
     auto step = [&](uint32_t s, auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
-        const bool active = !CHECK || (lane <= s && lane + nrows > s);
+        const bool in_range = !CHECK || (lane <= s && lane + nent > s);
         const uint32_t next_left = __builtin_amdgcn_mov_dpp(win_left, 0x134 /* wave_rol:1 */, 0xF, 0xF, true);
         const uint32_t next_b = __builtin_amdgcn_mov_dpp(win_b, 0x134, 0xF, 0xF, true);
-        const uint32_t h2 = __builtin_amdgcn_update_dpp(win_left, last_h2, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-        bc = __builtin_amdgcn_update_dpp(win_b, bc, 0x138, 0xF, 0xF, false);
+        const uint32_t codes = __builtin_amdgcn_update_dpp(win_left, last_codes, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+        bcs = __builtin_amdgcn_update_dpp(win_b, bcs, 0x138, 0xF, 0xF, false);
         win_left = next_left;
         win_b = next_b;
-        // next step's Eq word: the character my left neighbour has NOW (lane 0: the window's next row) -- requested here,
+        // next step's Eq words: the characters my left neighbour has NOW (lane 0: the window's next entry) -- requested here,
         // used one step on
-        const uint32_t bc_next = __builtin_amdgcn_update_dpp(next_b, bc, 0x138, 0xF, 0xF, false);
-        uint32_t eq_next;
-        asm volatile("ds_read_b32 %0, %1" : "=v"(eq_next) : "v"(peq_base + (bc_next << 2)) : "memory");
-        if (active) {
-            uint32_t Eq = eq_cur;
-            const uint32_t hm = h2 >> 1, hp = h2 & 1u;
-            const uint32_t Xv = Eq | Mv;
-            Eq |= hm;
-            const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-            uint32_t Ph = Mv | ~(Xh | Pv);
-            uint32_t Mh = Pv & Xh;
-            const uint32_t op = (Ph >> hb) & 1u, om = (Mh >> hb) & 1u;
-            Ph = (Ph << 1) | hp;
-            Mh = (Mh << 1) | hm;
-            Pv = Mh | ~(Xv | Ph);
-            Mv = Ph & Xv;
-            last_h2 = op | (om << 1);
-            fe += op - om - 1u; // F = D - r - c: one row down at a fixed column
+        const uint32_t bcs_next = __builtin_amdgcn_update_dpp(next_b, bcs, 0x138, 0xF, 0xF, false);
+        uint32_t eq_next[R];
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(eq_next[q]) : "v"(peq_base + (((bcs_next >> (8 * q)) & 0xffu) << 2)) : "memory");
+        uint32_t out_codes = last_codes;
+        uint32_t fe_q[R];
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) {
+            fe_q[q] = fe;
+            const bool active = in_range && (!CHECK || (s - lane) * R + q < nrows);
+            if (active) {
+                uint32_t Eq = eq_cur[q];
+                const uint32_t h2 = (codes >> (2 * q)) & 3u;
+                const uint32_t hm = h2 >> 1, hp = h2 & 1u;
+                const uint32_t Xv = Eq | Mv;
+                Eq |= hm;
+                const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                uint32_t Ph = Mv | ~(Xh | Pv);
+                uint32_t Mh = Pv & Xh;
+                const uint32_t op = (Ph >> hb) & 1u, om = (Mh >> hb) & 1u;
+                Ph = (Ph << 1) | hp;
+                Mh = (Mh << 1) | hm;
+                Pv = Mh | ~(Xv | Ph);
+                Mv = Ph & Xv;
+                out_codes = (out_codes & ~(3u << (2 * q))) | ((op | (om << 1)) << (2 * q));
+                fe += op - om - 1u; // F = D - r - c: one row down at a fixed column
+                fe_q[q] = fe;
+            }
         }
-        // (the Eq word has landed behind this wait: the value passes THROUGH it, or hipcc schedules its use in front of it)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eq_next)::"memory");
-        eq_cur = eq_next;
-        const uint32_t rot = __builtin_amdgcn_mov_dpp(acc, 0x134 /* wave_rol:1 */, 0xF, 0xF, true);
-        acc = is_out ? fe : rot;
+        last_codes = out_codes;
+        // (the Eq words have landed behind this wait: the values pass THROUGH it, or hipcc schedules their use in front of it)
+        if constexpr (R == 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eq_next[0])::"memory");
+        else if constexpr (R == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eq_next[0]), "+v"(eq_next[1])::"memory");
+        else if constexpr (R == 3)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eq_next[0]), "+v"(eq_next[1]), "+v"(eq_next[2])::"memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eq_next[0]), "+v"(eq_next[1]), "+v"(eq_next[2]), "+v"(eq_next[3])::"memory");
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) {
+            eq_cur[q] = eq_next[q];
+            const uint32_t rot = __builtin_amdgcn_mov_dpp(acc[q], 0x134 /* wave_rol:1 */, 0xF, 0xF, true);
+            acc[q] = is_out ? fe_q[q] : rot;
+        }
     };
     auto merge = [&](uint32_t &win, uint32_t fresh, bool upper) {
         const bool mine = lane / G == (upper ? 1u : 0u);
         win = mine ? fresh : win;
     };
 
-    const uint32_t steps = nrows ? nrows + 63 : 0;
-    uint64_t nxt_left = 0;
-    uint8_t nxt_b = 0;
+    const uint32_t steps = nent ? nent + 63 : 0;
+    Group nxt = {};
     if (steps) {
         __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-        const uint32_t v0 = validate(load_left(0), 0);
-        merge(win_left, to_code(v0), false);
-        merge(win_b, (uint32_t)load_b(0), false);
-        if (!failed) {
-            nxt_left = load_left(G);
-            nxt_b = load_b(G);
-        }
-        // the first step's Eq word: row 0's character is in lane 0 of the window; the other lanes' first rows come later and
-        // are requested by the step before
-        eq_cur = my_peq[win_b & 0xffu];
+        Group g0 = load_group(0);
+        uint32_t f0[R];
+        validate(g0, 0, f0);
+        merge(win_left, to_code(f0), false);
+        merge(win_b, pack_b(g0), false);
+        if (!failed) nxt = load_group(G);
+        // the first step's Eq words: entry 0's characters are in lane 0 of the window; the other lanes' first entries come
+        // later and are requested by the step before
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) eq_cur[q] = my_peq[(win_b >> (8 * q)) & 0xffu];
     }
-    uint32_t published = 0;
+    uint32_t published = 0; // entries handed over so far
     auto publish = [&](uint32_t done_steps) {
-        uint32_t done = done_steps > out_lane ? done_steps - out_lane : 0; // rows 0 .. done-1 are final
-        done = done < nrows ? done : nrows;
-        const uint32_t rr = published + ((lane - 2u * out_lane + done_steps - 1u - published) & 63u);
-        if (done_steps > 0 && rr < done)
-            __hip_atomic_store(my_rc + phys_r(rr + 1), ed_entry(acc, a.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t done = done_steps > out_lane ? done_steps - out_lane : 0; // entries 0 .. done-1 are final
+        done = done < nent ? done : nent;
+        const uint32_t e = published + ((lane - 2u * out_lane + done_steps - 1u - published) & 63u);
+        if (done_steps > 0 && e < done) {
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q)
+                if (e * R + q < nrows)
+                    __hip_atomic_store(my_rc + phys_r(e * R + q + 1), ed_entry(acc[q], a.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         published = done;
     };
     for (uint32_t s0 = 0; s0 < steps && !failed; s0 += G) {
-        const uint32_t fresh = validate(nxt_left, s0 + G);
+        uint32_t fr[R];
+        validate(nxt, s0 + G, fr);
         if (failed) break;
-        merge(win_left, to_code(fresh), true);
-        merge(win_b, (uint32_t)nxt_b, true);
+        merge(win_left, to_code(fr), true);
+        merge(win_b, pack_b(nxt), true);
         asm volatile("" : "+v"(win_left), "+v"(win_b));
         publish(s0);
-        nxt_left = load_left(s0 + 2 * G);
-        nxt_b = load_b(s0 + 2 * G);
+        nxt = load_group(s0 + 2 * G);
 
         const uint32_t n = steps - s0 < G ? steps - s0 : G;
-        const bool steady = s0 >= 63 && s0 + G - 1 < nrows; // every lane has a row in each of these G steps
+        const bool steady = s0 >= 63 && (s0 + G) * R <= nrows; // every lane has a whole entry in each of these G steps
         if (steady) {
 #pragma unroll 4
             for (uint32_t j = 0; j < G; ++j) step(s0 + j, std::false_type{});

@@ -645,8 +645,33 @@ __device__ __forceinline__ uint32_t park_tile_short(const ScanArgs &a, const Lds
                                                     uint32_t hi_t, uint64_t tile_off, uint32_t wave, uint32_t lane, bool count_only)
 {
     ShortTile<BLOCK, TILE> st;
-    const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane, (a.dense_enabled & 2u) != 0);
+    const bool sparse = (a.dense_enabled & 2u) != 0; // (wave-uniform; only ever set together with bit 0: a fill pass exists)
+    const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane, sparse);
     if (__ballot(cnt != 0) == 0) return 0; // (wave-uniform) the usual case on a large alphabet: nothing to scan, nothing to park
+    if (sparse && !count_only) {
+        // Few lanes hold a match: each reserves its own room (one LDS atomic instruction for the wave, a few lanes active) --
+        // no scan over the wave, no wave count: the fill pass, should the result turn out dense after all, counts for itself.
+        if (cnt != 0) {
+            const uint32_t addr = (uint32_t)(uintptr_t)tb.stage_cnt;
+            uint32_t base;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(addr), "v"(cnt) : "memory");
+            base -= tb.stage_seen;
+            if (base + cnt <= tb.stage_cap) { // (else: counted, not stored -- the ledger sees the overflow and the tile is dense)
+                uint32_t idx = base;
+#pragma unroll
+                for (uint32_t r = 0; r < ShortTile<BLOCK, TILE>::ROUNDS; ++r) {
+                    uint32_t x = st.e[r];
+                    const uint32_t p0 = st.first + r * 1024;
+                    while (x != 0) {
+                        const uint32_t j = (uint32_t)(__ffs((int)x) - 1);
+                        tb.stage[idx++] = tile_off + (uint64_t)(p0 + j);
+                        x &= x - 1;
+                    }
+                }
+            }
+        }
+        return 0;
+    }
     const uint32_t incl = wave_inclusive_scan(cnt);
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
     if (total == 0) return 0; // (wave-uniform)

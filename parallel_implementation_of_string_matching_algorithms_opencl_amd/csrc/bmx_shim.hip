@@ -685,7 +685,9 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
                 ctx->tile_cap = n_tiles;
             }
             ctx->last_fillable = true;
-            if (is_short) a.tile_count = ctx->d_tile_count, a.wave_count = ctx->d_wave_count; // the short-pattern scan leaves the counts itself
+            // the short-pattern scan leaves the counts itself -- unless matches are expected to be rare: then it spares itself the
+            // per-tile bookkeeping, and the fill pass, should the result be dense after all, counts in a launch of its own
+            if (is_short && !sparse) a.tile_count = ctx->d_tile_count, a.wave_count = ctx->d_wave_count;
         }
         const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
         if (v.stamps) { // diagnostic build: room for 8 words per wave
@@ -709,7 +711,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         ctx->last_grid = (int)grid;
         ctx->last_m = m;
         ctx->last_short = short_pattern(pat, m); // (the fill pass of a short pattern is ShortTile's, whatever kernel scanned)
-        ctx->last_counted = is_short;
+        ctx->last_counted = is_short && !sparse;
     } else {
         ctx->last_fillable = false;
     }
@@ -1081,8 +1083,16 @@ const EdVariant g_ed_variants[] = {
     BMX_ED(4, 512, 7), // 6
     BMX_ED(3, 256, 3), // 7
     // 8: the bit-parallel band (bmx_ed_bits_kernel.h): 2048 columns per wave, 32 per lane as two words of differences
-    {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits_kernel<32>, bmx::ed_bits_kernel<16>,
-     bmx::ED_BITS_LDS, 200, 34.0},
+    {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits_kernel<32, 1>, bmx::ed_bits_kernel<16, 1>,
+     bmx::ED_BITS_LDS, 190, 34.0},
+    // 9: ... two rows per step (a window entry = two rows); 10: four.  Measured at 64k x 64k (profiles/r03_ed_*.jsonl), ms at the
+    // best assumed lag: one row 2.80-2.97 (lag 180-200), two rows 2.58 (350-400), four 2.67 (800): a step is ~40 / 57 / 90
+    // instructions at ~5.5 cycles each for a lone wave (the recurrence is one dependent chain), so rows per step only
+    // amortise the ~17 instructions around it
+    {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits_kernel<32, 2>, bmx::ed_bits_kernel<16, 2>,
+     bmx::ED_BITS_LDS, 380, 28.5},
+    {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits_kernel<32, 4>, bmx::ed_bits_kernel<16, 4>,
+     bmx::ED_BITS_LDS, 800, 27.0},
 };
 constexpr int N_ED_VARIANTS = sizeof(g_ed_variants) / sizeof(g_ed_variants[0]);
 constexpr int ED_ONE_DIRECTION = 16; // flag on the variant number: tiles, from the top-left corner only

@@ -8,11 +8,11 @@ rng = np.random.default_rng(5)
 x = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 z = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 ctx = host.Context(0, library=host.exp_lib())  # the lag / group switches exist in libbmx_exp.so only
-for v, grp in ((8, 32), (8, 16), (4, 32), (4, 16)):
+for v, grp in ((8, 32), (9, 32), (9, 16), (10, 32), (10, 16), (4, 32)):
     ctx.set_ed_variant(v)
     ctx.set_knob("ed_group", grp)
     row = {}
-    for lag in (100, 140, 160, 180, 200, 220, 250, 300, 400):
+    for lag in (140, 180, 220, 260, 300, 350, 400, 500, 600, 800):
         ctx.set_knob("ed_lag", lag)
         ms = []
         for _ in range(4):
