@@ -221,9 +221,11 @@ int bmx_device_alloc(bmx_ctx *ctx, uint64_t bytes, void **d_ptr_out);
 
 /* Several patterns in ONE pass over a text resident in HBM (SURVEY.md s8 f3 in full: the reference re-uploads
  * the text and re-JITs its kernel for every query, BoyreMoore.cpp:213-256; here the text is fetched once per
- * tile and walked once per pattern, each with its own shift tables -- BoyreMoore.cpp:150-190 -- in LDS; a
- * pattern of nine and more characters over at most eight distinct symbols is walked with the 8-gram form of the
- * bad-symbol rule, as a single search of it would be).
+ * tile and walked once per pattern, each with its own shift tables -- BoyreMoore.cpp:150-190 -- in LDS; every
+ * pattern is walked the way a single search of it would be: the quad-SAD skip loop on texts over large alphabets,
+ * the 8-gram form of the bad-symbol rule for nine and more characters over at most eight distinct symbols,
+ * byte-wise otherwise).  The call does not synchronise the stream: it ends with the wait for the search's pinned
+ * status word, like bmx_search_device.
  * K = 1..BMX_MAX_MULTI patterns of ms[k] bytes.  On return d_match_positions holds pattern 0's matches in
  * ascending order, then pattern 1's, ...: pattern k's are the n_matches[k] entries from index first[k]
  * (n_matches and first: host arrays of K entries).  d_text, n, n_own, base_offset as in bmx_search_device.

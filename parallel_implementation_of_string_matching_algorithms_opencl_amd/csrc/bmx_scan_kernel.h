@@ -120,6 +120,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     // WALK 20 (several patterns in one pass): their tables, one blob, sit between the tile buffers and the rest
     uint8_t *multi_lds = smem + 2 * buf_bytes;
     constexpr bool MULTI = WALK == 20 || WALK == 21;
+    static_assert(!MULTI || (uint32_t)BLOCK * SAD_SEG >= TILE + 16, "the lanes' filter positions must cover a tile (multi-pattern quad-SAD walk)");
     const uint32_t multi_bytes = MULTI ? a.multi_bytes : 0u;
     if (MULTI)
         for (uint32_t i = tid * 16; i < multi_bytes; i += BLOCK * 16)
@@ -128,7 +129,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
     // built here as load_tables builds the single pattern's (minimum of m - 1 - j per hash through a u32 copy in the
     // still empty tile area), from the pattern bytes of the blob
     uint8_t *multi_q = multi_lds + multi_bytes;
-    const uint32_t multi_q_bytes = WALK == 21 ? (uint32_t)__popc(a.multi_qmask) * QGRAM_TABLE : 0u;
+    const uint32_t multi_q_bytes = WALK == 21 ? (uint32_t)__popc(a.multi_qmask & 0xffu) * QGRAM_TABLE : 0u;
     if constexpr (WALK == 21) {
         __syncthreads(); // the blob is in LDS
         uint32_t *s_q = reinterpret_cast<uint32_t *>(smem);
@@ -416,8 +417,18 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                         uint32_t hk = seg_lo + seg_len;
                         const uint64_t remk = a.multi_own_end[k] > tile_off ? a.multi_own_end[k] - tile_off : 0;
                         if (remk < (uint64_t)hk) hk = (uint32_t)remk;
-                        if (WALK == 21 && ((a.multi_qmask >> k) & 1u) != 0) { // (uniform) small alphabet, m >= 9: the 8-gram rule
-                            tk.qtab = multi_q + (uint32_t)__popc(a.multi_qmask & ((1u << k) - 1u)) * QGRAM_TABLE;
+                        if (((a.multi_qmask >> (8 + k)) & 1u) != 0) { // (uniform) text over a large alphabet: the quad-SAD skip loop
+                            // (round 3: the lanes own 80 filter positions of the tile each, whatever the pattern -- K x ~1,340
+                            // cycles of walk per tile instead of K byte-wise walks of ~2,900)
+                            const uint8_t *pe = tk.pat + mk;
+                            const uint32_t w = mk >= 4 ? (uint32_t)pe[-4] | ((uint32_t)pe[-3] << 8) | ((uint32_t)pe[-2] << 16) | ((uint32_t)pe[-1] << 24)
+                                                       : (uint32_t)tk.pat[0] | (mk > 1 ? (uint32_t)tk.pat[1] << 8 : 0u) | (mk > 2 ? (uint32_t)tk.pat[2] << 16 : 0u);
+                            tk.sad_a = __builtin_amdgcn_readfirstlane(w);
+                            const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
+                            const uint32_t hi_t = remk < (uint64_t)TILE ? (uint32_t)remk : TILE;
+                            walk_lane_sad<false>(a, tk, T, tid, lo_t, hi_t, tile_off);
+                        } else if (WALK == 21 && ((a.multi_qmask >> k) & 1u) != 0) { // (uniform) small alphabet, m >= 9: the 8-gram rule
+                            tk.qtab = multi_q + (uint32_t)__popc(a.multi_qmask & 0xffu & ((1u << k) - 1u)) * QGRAM_TABLE;
                             const uint8_t *pe = tk.pat + mk; // the pattern's last eight bytes as two little-endian words
                             tk.sad_a = __builtin_amdgcn_readfirstlane((uint32_t)pe[-4] | ((uint32_t)pe[-3] << 8) | ((uint32_t)pe[-2] << 16) | ((uint32_t)pe[-1] << 24));
                             tk.sad_b = __builtin_amdgcn_readfirstlane((uint32_t)pe[-8] | ((uint32_t)pe[-7] << 8) | ((uint32_t)pe[-6] << 16) | ((uint32_t)pe[-5] << 24));

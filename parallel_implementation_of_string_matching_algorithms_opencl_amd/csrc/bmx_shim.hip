@@ -887,7 +887,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     std::vector<uint8_t> blob;
     bmx::ScanArgs a;
     uint64_t n_starts_max = 0;
-    uint32_t qmask = 0;
+    uint32_t qmask = 0, many_symbols = 0, sadmask = 0;
     const uintptr_t addr = (uintptr_t)d_text;
     const uint64_t mis = addr & 15u;
     for (int k = 0; k < K; ++k) {
@@ -911,6 +911,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
             for (int i = 0; i < m; ++i)
                 if (!seen[(unsigned char)pats[k][i]]) seen[(unsigned char)pats[k][i]] = true, ++distinct;
             if (m >= 9 && distinct >= 2 && distinct <= 8) qmask |= 1u << k;
+            if (distinct > 4) many_symbols |= 1u << k;
         }
         const uint64_t n_starts = n < (uint64_t)m ? 0 : std::min<uint64_t>(n - (uint64_t)m + 1, n_own);
         a.multi_own_end[k] = mis + n_starts;
@@ -933,9 +934,16 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     }
     ctx->armed = false;
     if (ctx->multi_no_qgram) qmask = 0; // (libbmx_exp.so only: A/B runs)
-    if (qmask != 0) { // ... and only if the TEXT's alphabet is small (pick_variant)
+    {   // which walker per pattern, by the TEXT's alphabet as far as it is known (pick_variant's rule): large and spread like
+        // random text -> the quad-SAD skip loop; prose-like -> quad-SAD from m = 8; small -> the 8-gram rule from m = 9
         const int sigma = text_sigma(ctx, d_text, n);
         if (sigma > 8) qmask = 0;
+        for (int k = 0; k < K; ++k) {
+            const bool large = sigma > 0 ? sigma > 8 : ((many_symbols >> k) & 1u) != 0;
+            const bool uniform_like = sigma > 0 ? sigma > 64 : ((many_symbols >> k) & 1u) != 0;
+            if (large && (uniform_like || ms[k] >= 8) && !ctx->multi_no_qgram) sadmask |= 1u << k;
+        }
+        qmask &= ~sadmask;
     }
     const uint32_t q_bytes = (uint32_t)__builtin_popcount(qmask) * bmx::QGRAM_TABLE;
     {   // (the tables of long patterns can leave no room for the shift tables beside two 52 KiB tiles: byte-wise then)
@@ -976,7 +984,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     a.halo16 = ((uint32_t)(m_max - 1) + 15u) & ~15u;
     a.multi = ctx->d_multi;
     a.multi_bytes = (uint32_t)blob.size();
-    a.multi_qmask = qmask;
+    a.multi_qmask = qmask | (sadmask << 8);
     a.K = (uint32_t)K;
     uint32_t kp2 = 1;
     while ((int)kp2 < K) kp2 <<= 1;

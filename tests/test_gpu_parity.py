@@ -826,3 +826,35 @@ def test_two_searches_in_flight_on_two_streams(port):
         n = lanes[k][3].finish()
         assert np.array_equal(lanes[k][2][:n].cpu().numpy().astype(np.uint64), want[k])
         lanes[k][0].close()
+
+
+def test_three_way_on_the_gpu_box_hip_port_and_reference_build(ctx, port, reference):
+    """The GPU suite compares the HIP path with `port` (the C restatement); that `port` equals the REFERENCE BUILD
+    (oracle/_ref: the reference's own sources compiled in the build container, shipped as a built artefact) is otherwise
+    only asserted by the CPU suite.  Here all three meet on the GPU box, on random cases inside the reference's domain
+    (7-bit ASCII, m <= 99) and on the reduced configs: HIP == port == reference build."""
+    if reference is None:
+        pytest.skip("oracle/_ref/libbmref.so did not travel")
+    rng = np.random.default_rng(4242)
+    for _ in range(60):
+        alpha = int(rng.choice([2, 4, 20, 95]))
+        n = int(rng.integers(1, 400_000))
+        m = int(rng.integers(1, 99))
+        text = (rng.integers(0, alpha, n) + 32).astype(np.uint8)
+        if n > m and rng.random() < 0.8:
+            a = int(rng.integers(0, n - m))
+            pat = text[a:a + m].copy()
+            for p in rng.integers(0, n - m, 5):
+                text[p:p + m] = pat
+        else:
+            pat = (rng.integers(0, alpha, m) + 32).astype(np.uint8)
+        pat = pat.tobytes()
+        want = reference.search(text, pat)
+        assert np.array_equal(port.search(text, pat), want), (alpha, n, m)
+        assert np.array_equal(dev_search(ctx, text, pat), want), (alpha, n, m)
+    for name in ("cfg2_4GiB_m16", "cfg3_4GiB_m64_acgt"):
+        spec = corpus.scaled(corpus.CONFIGS[name], 6 * (1 << 20) + 13)
+        text = spec.host_text()
+        want = reference.search(text, spec.pattern())
+        assert np.array_equal(port.search(text, spec.pattern()), want)
+        assert np.array_equal(dev_search(ctx, text, spec.pattern()), want)

@@ -2,15 +2,14 @@
 # Round 3, call K2: the bench lines and tool outputs that go into profiles/ (final build of the round).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r03k2
+OUT=$R/gpurun_out/r03n
 mkdir -p "$OUT"
 cd "$R"
 (hostname; rocm-smi --showuniqueid 2>&1 | grep "Unique ID") > "$OUT/box.txt" 2>&1
-timeout -k 10 600 python -m pytest tests/test_edit_distance.py -m gpu -x -q > "$OUT/ed_tests.log" 2>&1; rc=$?
-tail -4 "$OUT/ed_tests.log"
-if [ $rc -ge 124 ]; then echo "ed tests killed"; exit 1; fi
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/tests.log" 2>&1; rc=$?
+tail -4 "$OUT/tests.log"
+if [ $rc -ge 124 ]; then echo "tests killed"; exit 1; fi
 timeout -k 10 300 python3 tools/ed_sweep.py > "$OUT/ed_sweep.jsonl" 2> "$OUT/ed_sweep.err" || exit 1
-timeout -k 10 300 python3 tools/ed_lag_sweep.py > "$OUT/ed_lag_sweep.jsonl" 2> "$OUT/ed_lag.err" || exit 1
 B="python3 bench.py"
 timeout -k 10 200 $B --steps 200 --warmup 20 > "$OUT/bench_cfg2.json" 2> "$OUT/bench_cfg2.err" &&
 timeout -k 10 200 $B --steps 20 --warmup 5 > "$OUT/bench_cfg2_driver_flags.json" 2>> "$OUT/bench.err" &&
@@ -28,4 +27,5 @@ timeout -k 10 200 python3 tools/dense_results.py --gib 1 --kind 1 --ms 1,2,3,4 >
 timeout -k 10 200 python3 tools/dense_results.py --gib 1 --kind 0 --ms 1,2,3 > "$OUT/dense_p95.jsonl" 2>> "$OUT/dense.err" &&
 timeout -k 10 300 python3 tools/multi_pattern.py --gib 4 --m 16 --kind 0 > "$OUT/multi_pattern_p95_m16.jsonl" 2> "$OUT/multi.err" &&
 timeout -k 10 300 python3 tools/multi_pattern.py --gib 4 --m 64 --kind 1 > "$OUT/multi_pattern_acgt_m64.jsonl" 2>> "$OUT/multi.err" &&
+timeout -k 10 200 python3 tools/stamp_report.py --gib 4 --m 2 --variant 84 > "$OUT/stamps_v84_m2.txt" 2>&1 &&
 echo done
