@@ -35,6 +35,10 @@
 
 #include "bmx_ed_band_kernel.h"
 
+// (the `#pragma unroll` loops over the R rows of a step degenerate for R = 1: hipcc reports "loop not unrolled" for them)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
+
 namespace bmx {
 
 constexpr uint32_t ED_BITS_W = 2048;          // columns per band: 64 lanes x 32 bits
@@ -267,8 +271,12 @@ __global__ __launch_bounds__(64) void ed_bits_kernel(const EdBandArgs a)
         const uint32_t n = steps - s0 < G ? steps - s0 : G;
         const bool steady = s0 >= 63 && (s0 + G) * R <= nrows; // every lane has a whole entry in each of these G steps
         if (steady) {
+            if constexpr (R == 1) {
 #pragma unroll 4
-            for (uint32_t j = 0; j < G; ++j) step(s0 + j, std::false_type{});
+                for (uint32_t j = 0; j < G; ++j) step(s0 + j, std::false_type{});
+            } else { // (a step of R rows is long enough as it is)
+                for (uint32_t j = 0; j < G; ++j) step(s0 + j, std::false_type{});
+            }
         } else {
             for (uint32_t j = 0; j < n; ++j) step(s0 + j, std::true_type{});
         }
@@ -293,3 +301,5 @@ __global__ __launch_bounds__(64) void ed_bits_kernel(const EdBandArgs a)
 }
 
 } // namespace bmx
+
+#pragma clang diagnostic pop
