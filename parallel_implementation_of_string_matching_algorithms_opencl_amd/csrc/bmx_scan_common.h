@@ -161,6 +161,9 @@ struct LdsTables {
     bool m4;
     // quad-SAD skip loop: the pattern's last four / the four before them, as little-endian words
     uint32_t sad_a, sad_b;
+    // ... on eight bytes (walk_lane_sad<true>): the pattern's last eight bytes as two words; a pattern shorter than eight: the whole
+    // pattern from its first byte on, zeros -- which the instruction leaves out of its sums -- behind it
+    uint32_t sad8_lo, sad8_hi;
 };
 
 // A match found by a walker (called under divergence).  Appending to HBM costs a global atomic with
@@ -863,7 +866,8 @@ __device__ __forceinline__ void walk_lane_sad(const ScanArgs &a, const LdsTables
     const uint32_t sbeg = (o & ~15u) + lane_idx * SAD_SEG; // this lane's first filter position: 16-byte aligned
     // filter positions that belong to a window to report: [lo_t + o, hi_t + o)
     if (sbeg >= hi_t + o || sbeg + SAD_SEG <= lo_t + o) return;
-    const uint32_t ref_a = tb.sad_a, ref_b = tb.sad_b; // pat[m-4..m), pat[m-8..m-4) as little-endian words
+    // F = 4: pat[m-4..m) (m < 4: the pattern, zeros behind); F = 8: pat[m-8..m-4) and pat[m-4..m) (m < 8: the pattern, zeros behind)
+    const uint32_t ref_a = F8 ? tb.sad8_hi : tb.sad_a, ref_b = F8 ? tb.sad8_lo : 0u;
     lds_c128 *q = (lds_c128 *)to_lds(T + sbeg);
     uint32_t d[22];
 #pragma unroll
@@ -901,7 +905,8 @@ __device__ __forceinline__ void walk_lane_sad(const ScanArgs &a, const LdsTables
         return ok;
     };
     const uint32_t covered = m < F ? m : F;
-    const bool exact = m < 4 ? no_zero_byte(ref_a, m) : (no_zero_byte(ref_a, 4) && (!F8 || no_zero_byte(ref_b, 4)));
+    const bool exact = !F8 ? no_zero_byte(ref_a, covered)
+                           : (no_zero_byte(ref_b, covered < 4 ? covered : 4) && (covered <= 4 || no_zero_byte(ref_a, covered - 4)));
     const uint32_t k0 = exact ? covered : 0u; // (wave-uniform)
     uint32_t next_ok = lo_t;
     if (q0 == 0) verify_stops<F8>(a, tb, T, sbeg, sbeg + 20, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
@@ -1015,6 +1020,7 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
     tb.m4 = m >= 4;
     tb.b_last = tb.p3 = tb.g1 = tb.g2 = tb.g3 = 0;
     tb.sad_a = tb.sad_b = 0;
+    tb.sad8_lo = tb.sad8_hi = 0;
     {   // the pattern's characters as a 128-bit set (walk_lane_bitmap): every lane ORs its share, the wave reduces
         uint32_t w[4] = {0, 0, 0, 0};
         for (uint32_t i = (tid & 63u); i < m; i += 64) {
@@ -1037,6 +1043,17 @@ __device__ __forceinline__ LdsTables load_tables(const ScanArgs &a, uint8_t *bas
     if (m >= 8)
         tb.sad_b = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.pat[m - 8] | ((uint32_t)a.tab.pat[m - 7] << 8) |
                                                   ((uint32_t)a.tab.pat[m - 6] << 16) | ((uint32_t)a.tab.pat[m - 5] << 24));
+    {
+        uint32_t lo = 0, hi = 0;
+        const uint32_t from = m >= 8 ? m - 8 : 0u, have = m >= 8 ? 8u : m;
+        for (uint32_t i = 0; i < have; ++i) {
+            const uint32_t c = a.tab.pat[from + i];
+            if (i < 4) lo |= c << (8 * i);
+            else hi |= c << (8 * (i - 4));
+        }
+        tb.sad8_lo = __builtin_amdgcn_readfirstlane(lo);
+        tb.sad8_hi = __builtin_amdgcn_readfirstlane(hi);
+    }
     if (SKIP) {
         tb.b_last = __builtin_amdgcn_readfirstlane((uint32_t)a.tab.bad[last_char & 127]);
         if (tb.m4) {

@@ -426,7 +426,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
                             tk.sad_a = __builtin_amdgcn_readfirstlane(w);
                             const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
                             const uint32_t hi_t = remk < (uint64_t)TILE ? (uint32_t)remk : TILE;
-                            walk_lane_sad<false>(a, tk, T, tid, lo_t, hi_t, tile_off);
+                            if (((a.multi_qmask >> (16 + k)) & 1u) != 0) { // (uniform) DNA-like text, m = 8..15: on the last EIGHT bytes
+                                tk.sad8_lo = __builtin_amdgcn_readfirstlane((uint32_t)pe[-8] | ((uint32_t)pe[-7] << 8) | ((uint32_t)pe[-6] << 16) | ((uint32_t)pe[-5] << 24));
+                                tk.sad8_hi = tk.sad_a; // (m >= 8 here: the host's rule)
+                                walk_lane_sad<true>(a, tk, T, tid, lo_t, hi_t, tile_off);
+                            } else {
+                                walk_lane_sad<false>(a, tk, T, tid, lo_t, hi_t, tile_off);
+                            }
                         } else if (WALK == 21 && ((a.multi_qmask >> k) & 1u) != 0) { // (uniform) small alphabet, m >= 9: the 8-gram rule
                             tk.qtab = multi_q + (uint32_t)__popc(a.multi_qmask & 0xffu & ((1u << k) - 1u)) * QGRAM_TABLE;
                             const uint8_t *pe = tk.pat + mk; // the pattern's last eight bytes as two little-endian words

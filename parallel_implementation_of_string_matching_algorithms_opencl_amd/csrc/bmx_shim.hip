@@ -109,7 +109,7 @@ struct Variant {
 #define BMX_TILE_LS(B, S, AUX, MODE, W, L, SI) BMX_TILE_G(B, S, AUX, MODE, W, L, SI, 0)
 #define BMX_TILE_G(B, S, AUX, MODE, W, L, SI, G) \
     {0, B, S, 2, L, SI, (MODE) == 5 || (MODE) == 8, (W) == 3 || (W) == 10, \
-     (W) == 7 ? 1 : ((W) == 3 || (W) == 9 ? 4 : ((W) == 8 || (W) == 10 ? 8 : 0)), \
+     (W) == 7 || (W) == 8 ? 1 : ((W) == 3 || (W) == 9 ? 4 : ((W) == 10 ? 8 : 0)), \
      bmx::scan_kernel<B, S, AUX, MODE, W, L, SI, G>, bmx::scan_kernel<B, S, AUX, MODE, 6, L, SI, G>, nullptr, nullptr, nullptr, nullptr}
 // a product geometry: with the fill pass for dense results (byte-wise walker / short-pattern walker on the same tiles)
 #define BMX_TILE_F(B, S, AUX, W) \
@@ -118,7 +118,7 @@ struct Variant {
      bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>}
 // ... and with static shares + a stolen tail (scan_kernel MODE 12); short patterns and the fill pass as in BMX_TILE_F
 #define BMX_TILE_S(B, S, AUX, W) \
-    {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 7 ? 1 : ((W) == 3 ? 4 : ((W) == 10 || (W) == 8 ? 8 : 0)), bmx::scan_kernel<B, S, AUX, 12, W>, \
+    {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 7 || (W) == 8 ? 1 : ((W) == 3 ? 4 : ((W) == 10 ? 8 : 0)), bmx::scan_kernel<B, S, AUX, 12, W>, \
      bmx::scan_kernel<B, S, AUX, 0, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>, \
      bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>, true}
 // a product geometry with clock stamps (MODE 5: per tile phase, MODE 8: two stamps around the loop): everything the
@@ -280,6 +280,7 @@ constexpr int VARIANT_QGRAM8 = 53;   // 8-gram walker, 76 KiB tiles
 constexpr int VARIANT_SKIP_STEAL = 82;     // skip loop on 36 KiB tiles, two workgroups per CU, static shares + a stolen tail
 constexpr int VARIANT_BIG_TILE_STEAL = 79; // ... with a stolen tail: the shorter the walk, the more a launch waits for its slowest workgroup
 constexpr int VARIANT_SAD = 87;      // quad-SAD skip loop on the last 4 pattern bytes, 76 KiB tiles, stolen tail
+constexpr int VARIANT_SAD8 = 88;     // ... on the last 8 (m >= 8)
 constexpr int VARIANT_BIG_TILE = 29; // 76 KiB tiles: +2 % on large alphabets, but room for 512 parked matches per tile only
 
 // `canonical`: the shift tables in use are the ones bmx_build_tables makes (always so when the caller
@@ -382,6 +383,13 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
     double expect = 1.0;
     for (int i = 0; i < m && expect < 1e6; ++i) expect *= distinct;
     if (expect < 128.0) return 0;
+    // DNA-like texts (4..8 symbols), m = 8..15: the quad-SAD skip loop on the pattern's last EIGHT bytes.  An 8-gram of such a
+    // text equals the pattern's last one once in 65,536 positions (one stop per tile), and the loop's cost does not depend on m,
+    // while the 8-gram WALKER shifts by m - 7 per window: 4 GiB ACGT, steady protocol, ms, walkers (4-gram at m = 8) / this: m = 8:
+    // 1.79 / 0.70, m = 9: 1.56 / 0.70, m = 10: 1.15 / 0.69, m = 12: 0.86 / 0.69, m = 14: 0.74 / 0.69, m = 16: 0.684 / 0.688, m = 20:
+    // 0.63 / 0.69, m >= 24: 0.61 / 0.69 (profiles/r03_acgt_sweep.jsonl).  Fewer than 4 symbols: every other window would stop.
+    // (m = 5..7: the same loop with the whole pattern as its reference, every stop a match)
+    if (canonical && m >= 5 && m < 16 && (sigma > 0 ? sigma : distinct) >= 4 && fits(VARIANT_SAD8)) return VARIANT_SAD8;
     if (canonical && m >= 9 && fits(VARIANT_QGRAM8)) return VARIANT_QGRAM8;
     if (canonical && m >= 6 && fits(VARIANT_QGRAM4)) return VARIANT_QGRAM4;
     return 2;
@@ -887,7 +895,8 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
     std::vector<uint8_t> blob;
     bmx::ScanArgs a;
     uint64_t n_starts_max = 0;
-    uint32_t qmask = 0, many_symbols = 0, sadmask = 0;
+    uint32_t qmask = 0, many_symbols = 0, sadmask = 0; // sadmask: bit k = quad-SAD walk for pattern k, bit 8 + k = ... on its last eight bytes
+    int distinct_of[BMX_MAX_MULTI] = {};
     const uintptr_t addr = (uintptr_t)d_text;
     const uint64_t mis = addr & 15u;
     for (int k = 0; k < K; ++k) {
@@ -912,6 +921,7 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
                 if (!seen[(unsigned char)pats[k][i]]) seen[(unsigned char)pats[k][i]] = true, ++distinct;
             if (m >= 9 && distinct >= 2 && distinct <= 8) qmask |= 1u << k;
             if (distinct > 4) many_symbols |= 1u << k;
+            distinct_of[k] = distinct;
         }
         const uint64_t n_starts = n < (uint64_t)m ? 0 : std::min<uint64_t>(n - (uint64_t)m + 1, n_own);
         a.multi_own_end[k] = mis + n_starts;
@@ -942,6 +952,9 @@ int bmx_search_device_multi(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64
             const bool large = sigma > 0 ? sigma > 8 : ((many_symbols >> k) & 1u) != 0;
             const bool uniform_like = sigma > 0 ? sigma > 64 : ((many_symbols >> k) & 1u) != 0;
             if (large && (uniform_like || ms[k] >= 8) && !ctx->multi_no_qgram) sadmask |= 1u << k;
+            // DNA-like text (4..8 symbols), m = 8..15: the quad-SAD loop on the last eight bytes (pick_variant's rule)
+            const int s_eff = sigma > 0 ? sigma : distinct_of[k];
+            if (!large && s_eff >= 4 && ms[k] >= 8 && ms[k] < 16 && !ctx->multi_no_qgram) sadmask |= 0x101u << k;
         }
         qmask &= ~sadmask;
     }

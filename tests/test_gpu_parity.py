@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 # bmx_shim.hip: the slots built into libbmx.so.  Every other slot (losing schedules, timing-only kernels whose
 # match lists are not valid) exists in libbmx_exp.so only and is refused by bmx_set_variant here.
-PRODUCT_VARIANTS = [0, 1, 2, 24, 25, 29, 53, 54, 79, 82, 87]
+PRODUCT_VARIANTS = [0, 1, 2, 24, 25, 29, 53, 54, 79, 82, 87, 88]
 QGRAM_VARIANTS = [24, 25, 53, 54]  # 4-gram and 8-gram walkers
 
 
@@ -551,7 +551,7 @@ def test_walker_follows_the_texts_alphabet(built, port):
     with host.Context(0) as c:
         # (up to 64 distinct bytes in the sample: prose-like -- the quad-SAD skip loop from m = 8, the skip loop below, the
         # short-pattern kernel up to m = 4; more: spread like random text -- quad-SAD from m = 3)
-        for text, slots in ((english, {9: 87, 6: 2, 16: 87, 3: 29, 2: 29}), (dna, {9: 53, 6: 54, 16: 53, 3: 29, 2: 29, 1: 0}),
+        for text, slots in ((english, {9: 87, 6: 2, 16: 87, 3: 29, 2: 29}), (dna, {9: 88, 12: 88, 7: 88, 6: 88, 5: 88, 16: 53, 40: 53, 4: 29, 3: 29, 2: 29, 1: 0}),
                             (p95, {9: 87, 6: 87, 16: 87, 4: 87, 3: 87, 2: 29, 1: 29})):
             pats = {}
             for m in slots:
@@ -575,7 +575,7 @@ def test_walker_follows_the_texts_alphabet(built, port):
 
 
 def test_stolen_tail_on_small_texts(built, port):
-    """The kernels that hand their last tiles out by ticket (variants 53, 54, 79, 82, 87) only do so when a workgroup has
+    """The kernels that hand their last tiles out by ticket (variants 53, 54, 79, 82, 87, 88) only do so when a workgroup has
     two dozen tiles and more -- half a GiB of text on 256 CUs, which only the full-size tests reach.  With the grid
     capped at a few workgroups (the `max_grid` switch of libbmx_exp.so: same sources, same kernels) texts of a few MiB go through the pool: sparse, clustered
     and dense results, a misaligned pointer, shard semantics, a tile count that is no multiple of anything, and twice
@@ -590,7 +590,8 @@ def test_stolen_tail_on_small_texts(built, port):
         with host.Context(0, library=host.exp_lib()) as c:
             c.set_knob("max_grid", grid)
             for variant, alpha, m in ((53, 4, 24), (53, 2, 64), (54, 4, 7), (79, 60, 40), (79, 4, 30), (82, 60, 10), (82, 60, 12), (87, 60, 16),
-                                     (87, 60, 5), (87, 60, 3), (87, 4, 20)):
+                                     (87, 60, 5), (87, 60, 3), (87, 4, 20), (88, 4, 12), (88, 60, 9), (88, 4, 6),
+                                     (88, 3, 5), (88, 4, 2)):
                 n = int(rng.integers(9_000_000, 12_000_000))
                 text = (rng.integers(0, alpha, n) + 65).astype(np.uint8)
                 pat = text[12345:12345 + m].copy()
