@@ -414,7 +414,8 @@ def main():
         torch.cuda.synchronize()
 
     # Before anything is counted, whatever --warmup says: (1) one search per lane -- the first search of a context on a
-    # text looks at the text's alphabet (one wait of ~20 us) and sets the kernel's LDS limit; (2) the device's clocks: the
+    # text goes by the pattern's symbols (the text's alphabet is known from the second on) and sets the kernel's LDS limit;
+    # (2) the device's clocks: the
     # first ~10 launches after the idle time of the set-up run 5-10 % slower (0.71, 0.72, 0.71, 0.70, 0.69, 0.68, 0.67,
     # 0.65 ms ... on config 2), which with --steps 20 --warmup 5 would be a fifth of the timed region.  --ramp-up 0 turns
     # it off; the line reports it (config.ramp_up_searches).

@@ -9,7 +9,7 @@ from parallel_implementation_of_string_matching_algorithms_opencl_amd import hos
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=300)
 ap.add_argument("--seed", type=int, default=12345)
-ap.add_argument("--variants", default="-1,0,1,2,24,25,29,53,54,79,82,87,88")  # -1: automatic choice; the slots of libbmx.so (BMX_LIB=exp + a longer list: the others)
+ap.add_argument("--variants", default="-1,0,1,2,24,25,29,53,54,79,82,87,88")  # -1: automatic choice; the slots of libbmx.so (host.use_library("exp") + a longer list: the others)
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 ctx = host.Context(0)
