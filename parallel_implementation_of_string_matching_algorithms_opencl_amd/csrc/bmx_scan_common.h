@@ -582,9 +582,47 @@ struct ShortTile {
 
     // this lane's matches among the window starts [lo_t, hi_t) of the tile; the masks stay in e[]
     __device__ __forceinline__ uint32_t count(const LdsTables &tb, const uint8_t *T, uint32_t lo_t, uint32_t hi_t, uint32_t wave,
-                                              uint32_t lane, bool sparse_ = false)
+                                              uint32_t lane, bool sparse_ = false, bool count_only = false)
     {
         setup(tb, lo_t, hi_t, wave, lane, sparse_);
+        // (wave-uniform) a workgroup that only counts (dense results), on a piece that lies wholly inside what is reported -- every
+        // piece but the text's first and last --: no masks, just how many.  m = 1: the equal bytes of a dword, exactly (eq_bytes),
+        // five instructions per dword; m = 2..4: sixteen sums per chunk, each capped at 1: what is left of 16 are the zeros -- 28
+        // instructions per chunk instead of the 36 that build a mask.  (One round after the other, and no call of the mask code in
+        // here: scheduled together, or with the edge case's mask inside the loop, the kernel -- 1024 threads: 128 registers per
+        // lane -- spilled: m = 2 at 1.59 instead of 0.77 ms.)
+        if (count_only && ref != 0 && lo_w == wave * PIECE && hi_w == (wave + 1) * PIECE) {
+            const u32x4 z = {0, 0, 0, 0};
+            uint32_t cnt = 0;
+            u32x4 v[ROUNDS];
+            uint32_t nx[ROUNDS];
+            const uint8_t *base = T + first;
+#pragma unroll
+            for (uint32_t r = 0; r < ROUNDS; ++r) {
+                v[r] = *(lds_c128 *)to_lds(base + r * 1024);
+                nx[r] = *(lds_c32 *)to_lds(base + r * 1024 + 16);
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < ROUNDS; ++r) {
+                uint32_t c;
+                if (m == 1) {
+                    c = (uint32_t)__popc(eq_bytes(v[r].x, p0)) + (uint32_t)__popc(eq_bytes(v[r].y, p0)) +
+                        (uint32_t)__popc(eq_bytes(v[r].z, p0)) + (uint32_t)__popc(eq_bytes(v[r].w, p0));
+                } else {
+                    const uint32_t w[5] = {v[r].x, v[r].y, v[r].z, v[r].w, nx[r]};
+                    uint32_t nonzero = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const u32x4 q = __builtin_amdgcn_mqsad_u32_u8((uint64_t)w[k] | ((uint64_t)w[k + 1] << 32), ref, z);
+                        nonzero += min(q.x, 1u) + min(q.y, 1u) + min(q.z, 1u) + min(q.w, 1u);
+                    }
+                    c = 16u - nonzero;
+                }
+                cnt += first + r * 1024 + 16 <= hi_w ? c : 0u; // (the last round's chunks past the piece are the next wave's)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return cnt;
+        }
         // Every round's chunk is requested before the first is looked at: one LDS latency per tile (several hundred cycles
         // while the next tile's DMA is landing), not one per round -- round 2 read, waited and tested round by round, and its
         // stamps put 47 % of a tile period into this walk.
@@ -620,7 +658,7 @@ struct ShortTile {
             for (uint32_t r = 0; r < ROUNDS; ++r) {
                 e[r] = 0;
                 if (mn[r] == 0) { // (per lane; the wave skips the block when no lane is in it)
-                    e[r] = mask_of_chunk(v[r], nx[r], r);
+                    e[r] = mask(T, r); // (the chunk once more out of LDS: keeping all the chunks in registers up to here spilled)
                     cnt += (uint32_t)__popc(e[r]);
                 }
             }
@@ -649,7 +687,7 @@ __device__ __forceinline__ uint32_t park_tile_short(const ScanArgs &a, const Lds
 {
     ShortTile<BLOCK, TILE> st;
     const bool sparse = (a.dense_enabled & 2u) != 0; // (wave-uniform; only ever set together with bit 0: a fill pass exists)
-    const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane, sparse);
+    const uint32_t cnt = st.count(tb, T, lo_t, hi_t, wave, lane, sparse, count_only);
     if (__ballot(cnt != 0) == 0) return 0; // (wave-uniform) the usual case on a large alphabet: nothing to scan, nothing to park
     if (sparse && !count_only) {
         // Few lanes hold a match: each reserves its own room (one LDS atomic instruction for the wave, a few lanes active) --

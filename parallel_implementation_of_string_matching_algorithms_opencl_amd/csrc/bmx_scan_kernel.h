@@ -470,7 +470,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs &a)
             if constexpr (WALK == 6) {
                 ShortTile<BLOCK, TILE> st;
                 const uint32_t lo_t = tile_off < a.first ? (uint32_t)(a.first - tile_off) : 0u;
-                tb.lane_cnt = st.count(tb, T, lo_t, rem < (uint64_t)TILE ? (uint32_t)rem : TILE, wave, lane);
+                tb.lane_cnt = st.count(tb, T, lo_t, rem < (uint64_t)TILE ? (uint32_t)rem : TILE, wave, lane, false, true);
             } else {
                 walk_tile();
             }
