@@ -24,6 +24,12 @@ int bmx_exp_set_knob(bmx_ctx *ctx, const char *name, int value);
 int bmx_probe_read(bmx_ctx *ctx, const void *d_text, uint64_t n, int block, int blocks_per_cu, int unroll, int nt,
                    int launches, float *ms_out, void *stream);
 
+/* Cycle counts (s_memtime) of the band in the middle of the forward pipeline of the last bmx_edit_distance_device call that
+ * ran the reworked bit-parallel band (ed variants 11, 12): out8 = {groups of unrolled steps, cycles inside them, cycles between
+ * them (validate, ring, hand-over, request), cycles of the whole loop, of which in validate (waiting included), steps per
+ * group, rows per step, steps of the band}. */
+int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out8);
+
 #ifdef __cplusplus
 }
 #endif

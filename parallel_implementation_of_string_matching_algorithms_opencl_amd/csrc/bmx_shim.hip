@@ -24,6 +24,7 @@
 #include "bmx_aux_kernels.h"
 #include "bmx_ed_band_kernel.h"
 #include "bmx_ed_bits_kernel.h"
+#include "bmx_ed_bits2_kernel.h"
 #include "bmx_ed_kernel.h"
 #ifdef BMX_EXPERIMENTS
 #include "bmx_scan_ring_kernel.h"
@@ -180,6 +181,7 @@ struct bmx_ctx {
     uint64_t last_text_n = 0;
     int last_variant = 0;    // what the most recent search ran (bmx_scan_geometry reports it)
     int ed_variant = 0;      // edit-distance tile shape (bmx_set_ed_variant)
+    uint64_t ed_stamps[8] = {}; // libbmx_exp.so: cycle counts of one band of the last band-pipeline run
     float ed_last_ms = -1.0f;
     void *ed_ws = nullptr;   // band pipeline workspace, kept between calls while it is small
     uint64_t ed_ws_bytes = 0;
@@ -1114,6 +1116,12 @@ const EdVariant g_ed_variants[] = {
      bmx::ED_BITS_LDS, 380, 28.5},
     {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits_kernel<32, 4>, bmx::ed_bits_kernel<16, 4>,
      bmx::ED_BITS_LDS, 800, 27.0},
+    // 11, 12: the bit-parallel band with the hand-over, the edge collector and the row windows out of the step
+    // (bmx_ed_bits2_kernel.h): two rows / one row per step
+    {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits2_kernel<32, 2>, bmx::ed_bits2_kernel<16, 2>,
+     bmx::ed_bits2_lds(32, 2), 380, 20.5},
+    {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits2_kernel<32, 1>, bmx::ed_bits2_kernel<16, 1>,
+     bmx::ed_bits2_lds(32, 1), 190, 25.0},
 };
 constexpr int N_ED_VARIANTS = sizeof(g_ed_variants) / sizeof(g_ed_variants[0]);
 constexpr int ED_ONE_DIRECTION = 16; // flag on the variant number: tiles, from the top-left corner only
@@ -1132,7 +1140,8 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     const uint32_t bands = (uint32_t)((la + W - 1) / W);
     // [right columns: 2 x (bands + 1) x (lb + 1) entries of 8 B | cut rows: 2 x bands x (W + 1) | cut | err | result]
     const uint64_t rc_entries = 2ull * (bands + 1) * (lb + 1), stair_words = 2ull * bands * (W + 1);
-    const uint64_t bytes = rc_entries * sizeof(uint64_t) + (stair_words + bands + 2) * sizeof(uint32_t);
+    const uint64_t stamp_at = (rc_entries * sizeof(uint64_t) + (stair_words + bands + 2) * sizeof(uint32_t) + 7) / 8 * 8;
+    const uint64_t bytes = stamp_at + 8 * sizeof(uint64_t);
     if (bytes > ED_BAND_WS_LIMIT || la + lb >= (1ull << 31)) return BMX_OK; // (the kernel's F = D - r - c is an int32)
     // Workspace: kept in the context between calls while it is small (a fresh hipMalloc + hipFree per
     // call costs 0.3 ms next to a 4 ms kernel).  Entries are valid only with this call's tag; tags are
@@ -1186,6 +1195,9 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     uint32_t *d_result = a.err + 1;
     a.tag = tag;
     a.lag = lag;
+#ifdef BMX_EXPERIMENTS
+    a.stamps = (uint64_t *)((char *)ws + stamp_at);
+#endif
     // generous: 10 s + 100x the time the tile schedule would need (100 MHz ticks)
     a.timeout_ticks = 1000000000ull + (uint64_t)((double)la * (double)lb / 2.0e9 * 100.0);
     const int slot = (int)(ctx->n_timed % bmx_ctx::EV_RING);
@@ -1210,6 +1222,9 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     if (e == hipSuccess) e = hipEventRecord(ctx->ev1[slot], stream);
     uint32_t h_tail[2] = {0, 0}; // err, result
     if (e == hipSuccess) e = hipMemcpyAsync(h_tail, a.err, sizeof h_tail, hipMemcpyDeviceToHost, stream);
+#ifdef BMX_EXPERIMENTS
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->ed_stamps, a.stamps, sizeof ctx->ed_stamps, hipMemcpyDeviceToHost, stream);
+#endif
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e == hipSuccess) (void)hipEventElapsedTime(&ctx->ed_last_ms, ctx->ev0[slot], ctx->ev1[slot]);
     if (!keep) (void)hipFree(ws);
@@ -1547,6 +1562,13 @@ int bmx_search_ranges(bmx_ctx *ctx_in, const char *text, uint64_t n, const char 
 #ifdef BMX_EXPERIMENTS
 // libbmx_exp.so only: the measurement / test switches of a context (round 2 read them from the environment on every call,
 // in the product library too).  Returns BMX_ERR_ARG for an unknown name.
+int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out8)
+{
+    if (!ctx || !out8) return BMX_ERR_ARG;
+    for (int i = 0; i < 8; ++i) out8[i] = ctx->ed_stamps[i];
+    return BMX_OK;
+}
+
 int bmx_exp_set_knob(bmx_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return BMX_ERR_ARG;

@@ -117,6 +117,7 @@ EXP_SYMBOLS = [
     ("bmx_exp_set_knob", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("bmx_probe_read", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_float), C.c_void_p]),
+    ("bmx_exp_ed_stamps", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
 ]
 
 _lib = None
@@ -220,6 +221,13 @@ class Context:
     def set_knob(self, name: str, value: int):
         """libbmx_exp.so only (bmx_exp_set_knob): max_grid, no_dense, no_text_sample, multi_no_qgram, ed_lag, ed_group, sa_flags."""
         self._chk(self._L.bmx_exp_set_knob(self._h, name.encode(), int(value)), "bmx_exp_set_knob")
+
+    def ed_stamps(self):
+        """libbmx_exp.so only (bmx_exp_ed_stamps): cycle counts of one band of the last edit distance (ed variants 11, 12)."""
+        out = (C.c_uint64 * 8)()
+        self._chk(self._L.bmx_exp_ed_stamps(self._h, out), "bmx_exp_ed_stamps")
+        keys = ["groups", "cycles_in_steps", "cycles_between", "cycles_loop", "cycles_validate", "steps_per_group", "rows_per_step", "band_steps"]
+        return dict(zip(keys, [int(v) for v in out]))
 
     def __del__(self):
         try:

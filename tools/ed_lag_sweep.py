@@ -8,15 +8,25 @@ rng = np.random.default_rng(5)
 x = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 z = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 ctx = host.Context(0, library=host.exp_lib())  # the lag / group switches exist in libbmx_exp.so only
-for v, grp in ((8, 32), (9, 32), (9, 16), (10, 32), (10, 16), (4, 32)):
+sel = [tuple(int(t) for t in a.split(':')) for a in sys.argv[2:]] or [(11, 32), (11, 16), (12, 32), (12, 16), (9, 32), (4, 32)]
+for v, grp in sel:
     ctx.set_ed_variant(v)
     ctx.set_knob("ed_group", grp)
     row = {}
-    for lag in (140, 180, 220, 260, 300, 350, 400, 500, 600, 800):
+    for lag in (100, 140, 180, 220, 260, 300, 350, 400, 500, 600, 800):
         ctx.set_knob("ed_lag", lag)
         ms = []
         for _ in range(4):
             d = ctx.edit_distance_device(x, z)
             ms.append(ctx.last_edit_distance_ms())
         row[lag] = round(min(ms[1:]), 3)
-    print(json.dumps({"variant": v, "group": grp, "distance": d, "ms_by_lag": row}), flush=True)
+    out = {"variant": v, "group": grp, "distance": d, "ms_by_lag": row}
+    if v in (11, 12):  # where the middle band's cycles went, at the default lag
+        ctx.set_knob("ed_lag", -1)
+        ctx.edit_distance_device(x, z)
+        st = ctx.ed_stamps()
+        if st["groups"]:
+            st["cycles_per_step"] = round(st["cycles_in_steps"] / (st["groups"] * st["steps_per_group"]), 1)
+            st["cycles_between_per_group"] = round(st["cycles_between"] / st["groups"], 1)
+        out["stamps_middle_band_default_lag"] = st
+    print(json.dumps(out), flush=True)
