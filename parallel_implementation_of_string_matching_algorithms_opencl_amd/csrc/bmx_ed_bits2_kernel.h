@@ -233,6 +233,8 @@ __global__ __launch_bounds__(64) void ed_bits2_kernel(const EdBandArgs a)
             chars[q] = __builtin_amdgcn_update_dpp(ent[q], chars[q], 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
         uint32_t eq_next[R];
         eq_request(eq_next);
+        // (the rows below start from Pv / Mv: passed through here, they cannot be scheduled in front of the requests)
+        asm volatile("" : "+v"(Pv), "+v"(Mv));
 #pragma unroll
         for (uint32_t q = 0; q < R; ++q) {
             // the horizontal differences that enter my columns on this row: top bits of the left neighbour's words of its

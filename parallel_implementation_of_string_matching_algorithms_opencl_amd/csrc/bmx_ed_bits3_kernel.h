@@ -1,0 +1,512 @@
+// bmx_ed_bits3_kernel.h -- Levenshtein distance: the bit-parallel band of bmx_ed_bits2_kernel.h with a HELPER wave.
+//
+// Cycle counts of one band of ed_bits2_kernel<32, 2> (bmx_exp_ed_stamps, profiles/r03_ed_lag_sweep_bits2_stamps.jsonl): 227 per
+// step of two rows, and 1,760 BETWEEN two groups of 32 steps -- validating the next group of the band in front, turning it into
+// edge bits, handing the own edge over (LDS round trips, a prefix sum, 64-bit addresses, HBM stores) -- a fifth of the time, on the
+// one wave whose dependent chain IS the critical path.  And the look-ahead of those groups (2 G entries requested, G handed over
+// at a time) is what keeps a band ~190 steps behind the one in front where the systolic skew alone would be 63.
+//
+// Here a band is a workgroup of TWO waves on two SIMDs of a CU:
+//   wave 0 (main)    only steps: per step one ring entry with the band edge's bits (ds_read_b128), its characters two steps ahead
+//                    (ds_read_b32 from a ring of characters: lane l reads entry s + 2 - l, so the characters need no DPP chain
+//                    either), the Eq words a step ahead, R rows of the recurrence, its Ph / Mh words into the outgoing ring.
+//                    Per group of G steps: two LDS flag words checked (cached: read again only when they do not suffice), one written.
+//   wave 1 (helper)  polls the band in front (HBM entries {F, tag}), turns a batch of G entries into ring entries, and hands the
+//                    main wave's finished groups over (edge bit -> differences -> prefix sum -> {F, tag} to HBM), whichever is
+//                    possible; never blocks on one while the other is due.
+// Between them, in LDS: feed ring (4 G entries of {P0, P1, M0, M1} + one mirrored), character ring (256 entries + G mirrored), the
+// outgoing ring per lane (two groups deep), and three counters: batches fed, groups stepped, groups handed over.  LDS instructions
+// of a wave complete in order, so "data, then counter" needs no wait on the writer's side beyond what orders its own instructions.
+// What goes to HBM is what went there before ({F, tag} per row): the value bands, the meet kernel and the cut rows do not change.
+//
+// Reference: EditDistance-1/EditDistance-1/kernal.cl:5-56 + EditDistance-1.cpp:278-345; recurrence as sequential.c:18-46.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "bmx_ed_bits2_kernel.h"
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
+
+namespace bmx {
+
+constexpr uint32_t ED_BITS3_CHARS = 512; // entries of the character ring
+constexpr uint32_t ed_bits3_lds(uint32_t group, uint32_t rows)
+{
+    // Eq table | feed ring | character ring | counters | outgoing rings
+    return (ED_BITS2_PEQ_WORDS + (8 * group + 1) * 4 + (ED_BITS3_CHARS + group) + 8 + 4 * (group * rows / 32) * 128) * 4;
+}
+
+// X: timing experiments (libbmx_exp.so; the distance is then WRONG): 1 no writes to the outgoing ring, 2 no Eq requests, 4 row_shr
+// instead of wave_shr in the hand to the right, 8 no feed-ring / character-ring requests, 16 no hand to the right at all
+template <int GROUP, int R, int X = 0>
+__global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
+{
+    static_assert(R == 1 || R == 2, "a feed-ring entry is four words: R <= 2 rows");
+    static_assert((GROUP == 16 || GROUP == 32) && GROUP * R % 32 == 0, "a group is whole chunks of 32 rows of the outgoing edge");
+    constexpr uint32_t W = ED_BITS2_W;
+    constexpr uint32_t G = GROUP;                      // steps per group (a step = an entry = R rows)
+    constexpr uint32_t FEED = 8 * G;                   // entries of the feed ring
+    constexpr uint32_t NCH = G * R / 32;               // chunks of 32 rows per group
+    constexpr uint32_t OUT_HALF = NCH * 128;           // words of one of the four slots of the outgoing ring: [chunk][lane][+1 bits | -1 bits]
+    extern __shared__ uint32_t ed_lds[];
+    uint32_t *const peq = ed_lds;                            // [256][64]
+    uint32_t *const feed = peq + ED_BITS2_PEQ_WORDS;         // [FEED + 1] x {P0, P1, M0, M1}
+    uint32_t *const crng = feed + (FEED + 1) * 4;            // [512 + G] characters of an entry: c0 << 8 | c1 << 24
+    uint32_t *const flags = crng + ED_BITS3_CHARS + G;       // [0] batches fed, [1] groups stepped, [2] groups handed over, [3] failed
+    uint32_t *const outw = flags + 8;                        // [4][OUT_HALF]
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool helper = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0;
+    const bool mirror = blockIdx.x >= a.bands;               // wave-uniform
+    const uint32_t Jt = blockIdx.x - (mirror ? a.bands : 0); // band in pipeline order
+    const uint32_t J = mirror ? a.bands - 1 - Jt : Jt;       // physical band
+    const uint32_t col0 = J * W;
+    const uint32_t ncols = a.la - col0 < W ? a.la - col0 : W;
+    const uint32_t nrows = mirror ? a.lb - a.cut[J] : a.cut[J];
+    const uint32_t nent = (nrows + R - 1) / R; // entries = steps a lane takes
+    const uint32_t steps = nent ? nent + 63 : 0;
+    const uint32_t ngroups = (steps + G - 1) / G;
+    auto phys_r = [&](uint32_t rr) { return mirror ? a.lb - rr : rr; };
+    auto phys_c = [&](uint32_t cc) { return mirror ? col0 + ncols - cc : col0 + cc; };
+
+    const int dir = mirror ? 1 : 0;
+    uint64_t *const my_rc = a.rc[dir] + (uint64_t)(mirror ? J : J + 1) * (a.lb + 1);
+    const uint64_t *const prev_rc = a.rc[dir] + (uint64_t)(mirror ? J + 1 : J) * (a.lb + 1);
+    const uint32_t out_lane = (ncols - 1) / 32, out_bit = (ncols - 1) % 32; // the band's right edge
+
+    // the Eq table: zeroed by both waves, then every lane of the main wave sets the bits of its 32 columns in its own column
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(outw - ed_lds); i += 128) ed_lds[i] = 0u;
+    __syncthreads();
+    if (!helper) {
+        for (uint32_t k = 0; k < 32; ++k) {
+            const uint32_t cc = lane * 32 + k;
+            if (cc < ncols) {
+                const uint32_t ch = a.a[mirror ? col0 + ncols - 1 - cc : col0 + cc];
+                peq[ch * 64 + lane] |= 1u << k; // (padding columns match nothing)
+            }
+        }
+        if (lane == 0) my_rc[phys_r(0)] = ed_entry(0u, a.tag); // my far edge on the table's edge row
+    }
+    __syncthreads();
+    if (steps == 0) { // no rows on my side of the cut: the cut row is the table's edge row
+        if (!helper) {
+            uint32_t *srow = a.stair_row[dir] + (uint64_t)J * (W + 1);
+            for (uint32_t cc = lane; cc <= ncols; cc += 64) srow[phys_c(cc) - col0] = 0u;
+        }
+        return;
+    }
+
+    const uint64_t t_start = wall_clock64();
+    const uint32_t flags_addr = (uint32_t)(uintptr_t)flags;
+    auto flags_read4 = [&]() { // all four counters (one instruction, same address in all lanes)
+        ed_u32x4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flags_addr) : "memory");
+        return v;
+    };
+    auto flag_write = [&](uint32_t k, uint32_t v) { // behind everything this wave has written to LDS before
+        asm volatile("ds_write_b32 %0, %1" : : "v"(flags_addr + 4u * k), "v"(v) : "memory");
+    };
+    // a wait that does not end: *err for the other bands, the LDS flag for the other wave
+    auto give_up = [&]() {
+        flag_write(3, 1u);
+        if (lane == 0) __hip_atomic_store(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto hopeless = [&]() {
+        return __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || wall_clock64() - t_start > a.timeout_ticks;
+    };
+
+    if (helper) {
+        // ---------------------------------------------------------------- helper wave
+        auto row_at = [&](uint32_t e, uint32_t q) {
+            const uint32_t rr = e * R + q;
+            return rr < nrows ? rr : nrows - 1; // (clamped: a row past the end is never consumed)
+        };
+        auto char_at = [&](uint32_t rr) { return a.b[mirror ? a.lb - 1 - rr : rr]; };
+        // batch k = entries (k - 1) G + 2 ... k G + 1: what the main wave reads up to the last step of group k - 1
+        // (batch 0 = entries 0 and 1, in the last two lanes; lane i of the first G holds entry (k - 1) G + 2 + i)
+        const uint32_t nbatches = ngroups + 1;
+        struct Batch {
+            uint64_t left[R];
+            uint8_t b[R];
+        };
+        auto entry_of = [&](uint32_t k) { return (k - 1u) * G + 2u + (lane & (G - 1)); }; // (wraps below 0 in batch 0)
+        auto load_batch = [&](uint32_t k) {
+            Batch g;
+            uint32_t e = entry_of(k);
+            e = (int32_t)e < 0 ? 0u : e;
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q) {
+                g.left[q] = __hip_atomic_load(prev_rc + phys_r(row_at(e, q) + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g.b[q] = char_at(row_at(e, q));
+            }
+            return g;
+        };
+        uint32_t prev_f = 0u; // F at vertex (0, c0): the table's edge row
+        auto to_rings = [&](const Batch &g, uint32_t k) {
+            const uint32_t e = entry_of(k);
+            const bool real = (int32_t)e >= 0;
+            uint32_t f[R];
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q) f[q] = (uint32_t)g.left[q];
+            uint32_t up = __builtin_amdgcn_update_dpp(0, (int)f[R - 1], 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+            up = ((lane & (G - 1)) == 0 || e == 0) ? prev_f : up;
+            prev_f = __builtin_amdgcn_readlane(f[R - 1], G - 1);
+            uint32_t w[4] = {0u, 0u, 0u, 0u}, cw = 0u;
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q) {
+                const int32_t d = (int32_t)f[q] - (int32_t)(q == 0 ? up : f[q - 1]); // -2, -1, 0: D[r] - D[r-1] = d + 1
+                w[q] = d == 0 ? 0x80000000u : 0u;                                   // bit 31: where v_alignbit looks
+                w[2 + q] = d == -2 ? 0x80000000u : 0u;
+                cw |= ((uint32_t)g.b[q] << 8) << (16 * q);
+            }
+            if (lane < G && real) {
+                const uint32_t fs = e & (FEED - 1), cs = e & (ED_BITS3_CHARS - 1);
+                ed_u32x4 *dst = reinterpret_cast<ed_u32x4 *>(feed) + fs;
+                const ed_u32x4 v = {w[0], w[1], w[2], w[3]};
+                *dst = v;
+                if (fs == 0) dst[FEED] = v; // a group's last step reads one entry on: slot 0 again behind the end
+                crng[cs] = cw;
+                if (cs < G) crng[cs + ED_BITS3_CHARS] = cw; // a group's steps read G entries from any slot on
+            }
+        };
+        uint32_t edge_f = 0u; // F at the band's right edge on the last row handed over
+        auto publish = [&](uint32_t p) {
+            const uint32_t st = p * G + lane;
+            const uint32_t e = st - out_lane;
+            const bool have = lane < G && st >= out_lane && e < nent;
+            // row r of a chunk is bit 31 - r of the two words the band's last lane wrote for it (the same words for all lanes)
+            const uint32_t *src = outw + (p & 3u) * OUT_HALF + ((lane & (G - 1)) * R / 32) * 128 + out_lane * 2;
+            const uint32_t wp = src[0], wm = src[1];
+            int32_t d[R];
+            int32_t tot = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q) {
+                const bool ok = have && e * R + q < nrows;
+                const uint32_t bit = 31u - (((lane & (G - 1)) * R + q) & 31u);
+                d[q] = ok ? (int32_t)((wp >> bit) & 1u) - (int32_t)((wm >> bit) & 1u) - 1 : 0;
+                tot += d[q]; // F = D - r - c: one row down at a fixed column
+            }
+            const uint32_t incl = ed_wave_inclusive_scan((uint32_t)tot);
+            uint32_t f = edge_f + incl - (uint32_t)tot;
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q) {
+                f += (uint32_t)d[q];
+                if (have && e * R + q < nrows)
+                    __hip_atomic_store(my_rc + phys_r(e * R + q + 1), ed_entry(f, a.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            edge_f += __builtin_amdgcn_readlane(incl, 63);
+        };
+
+        uint32_t fed = 0, handed = 0, polls = 0;
+        Batch nxt = load_batch(0);
+        bool requested = true;
+        while (fed < nbatches || handed < ngroups) {
+            const ed_u32x4 fl = flags_read4();
+            const uint32_t stepped = __builtin_amdgcn_readfirstlane(fl.y);
+            if (__builtin_amdgcn_readfirstlane(fl.w) != 0) return;
+            bool progress = false;
+            if (handed < ngroups && stepped > handed) { // the band behind waits for this: first
+                publish(handed);
+                ++handed;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the ring has been read: the main wave may write it again)
+                flag_write(2, handed);
+                progress = true;
+            }
+            if (fed < nbatches && fed <= stepped + 7) { // the rings have room for batch `fed`
+                if (!requested) {
+                    nxt = load_batch(fed);
+                    requested = true;
+                }
+                bool bad = false;
+#pragma unroll
+                for (uint32_t q = 0; q < R; ++q) bad = bad || (uint32_t)(nxt.left[q] >> 32) != a.tag;
+                if (__ballot(bad) == 0) {
+                    to_rings(nxt, fed);
+                    ++fed;
+                    flag_write(0, fed);
+                    progress = true;
+                    if (fed < nbatches) nxt = load_batch(fed);
+                    else requested = false;
+                } else {
+                    requested = false; // ask again next time round
+                }
+            }
+            if (!progress) {
+                if ((++polls & 63u) == 0 && hopeless()) {
+                    give_up();
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- main wave
+    uint32_t Pv = ~0u, Mv = 0u;    // row 0: D[0][c] = c
+    uint32_t ph_out[R], mh_out[R]; // what my columns handed to the right in my previous step
+    uint32_t eq_cur[R];
+#pragma unroll
+    for (uint32_t q = 0; q < R; ++q) ph_out[q] = mh_out[q] = eq_cur[q] = 0u;
+    uint32_t chars_nxt = 0u;     // before step s: the characters of entry s + 1 - lane (my next step's)
+    ed_u32x4 ent = {0, 0, 0, 0}; // before step s: feed-ring entry s (the band edge's bits for lane 0)
+    const uint32_t lane_off = (uint32_t)(uintptr_t)peq + lane * 4u;
+    const uint32_t feed_base = (uint32_t)(uintptr_t)feed;
+    const uint32_t crng_base = (uint32_t)(uintptr_t)crng;
+    const uint32_t out_base = (uint32_t)(uintptr_t)outw + lane * 8u;
+    uint32_t feed_addr = feed_base, chars_addr = crng_base, out_addr = out_base;
+    uint32_t acc_p = 0u, acc_m = 0u; // the band-edge bit of my Ph / Mh words of the last 32 rows, oldest row on top
+    const uint32_t edge_up = 31u - out_bit; // (the narrow band's edge bit is not bit 31: moved there first)
+
+    auto eq_request = [&](uint32_t (&dst)[R], uint32_t chars) {
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) {
+            uint32_t addr;
+            if (q == 0)
+                asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
+                             : "=v"(addr)
+                             : "v"(chars), "v"(lane_off));
+            else
+                asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+                             : "=v"(addr)
+                             : "v"(chars), "v"(lane_off));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(dst[q]) : "v"(addr) : "memory");
+        }
+    };
+    // (LDS words requested by inline asm have landed behind this wait: the values pass THROUGH it, or hipcc schedules their use in
+    // front of it.)  BEHIND = LDS instructions issued after the requests that need not be waited for (in-order completion): the
+    // write of a chunk of the outgoing edge comes last in its step.
+    auto settle = [&](uint32_t (&w)[R], ed_u32x4 &e, uint32_t &c, auto behind) {
+        constexpr uint32_t BEHIND = decltype(behind)::value;
+        static_assert(BEHIND <= 1, "");
+        if constexpr (R == 1 && BEHIND == 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(e), "+v"(c)::"memory");
+        else if constexpr (R == 1)
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w[0]), "+v"(e), "+v"(c)::"memory");
+        else if constexpr (BEHIND == 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(e), "+v"(c)::"memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w[0]), "+v"(w[1]), "+v"(e), "+v"(c)::"memory");
+    };
+
+    // One step: R rows of my 32 columns.  JC = the step's number within its group where the group is unrolled (ring addresses are
+    // then immediates); else 0 and the addresses move.
+    auto step = [&](uint32_t s, auto check_tag, auto jc, auto narrow_tag) {
+        constexpr bool CHECK = decltype(check_tag)::value;
+        constexpr uint32_t JC = decltype(jc)::value;
+        constexpr bool NARROW = decltype(narrow_tag)::value; // the band's last column is not bit 31 of a lane
+        const bool in_range = !CHECK || (lane <= s && lane + nent > s);
+        uint32_t chars_far;
+        ed_u32x4 ent_far;
+        if constexpr (X & 8) {
+            chars_far = chars_nxt;
+            ent_far = ent;
+        } else {
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(chars_far) : "v"(chars_addr), "n"(JC * 4) : "memory");        // entry s + 2 - lane
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ent_far) : "v"(feed_addr), "n"((JC + 1) * 16) : "memory"); // entry s + 1
+        }
+        uint32_t eq_next[R];
+        if constexpr (X & 2) {
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q) eq_next[q] = eq_cur[q] ^ chars_nxt;
+        } else {
+            eq_request(eq_next, chars_nxt);
+        }
+        // (the rows below start from Pv / Mv: passed through here, they cannot be scheduled in front of the requests -- hipcc moved
+        // the step's first row up there, and the step's wait then came ~40 cycles after the last request instead of ~130)
+        asm volatile("" : "+v"(Pv), "+v"(Mv));
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) {
+            // the horizontal differences that enter my columns on this row: top bits of the left neighbour's words of its
+            // previous step; lane 0 (left alone by the DPP move): the band edge's
+            constexpr int SHR = (X & 4) ? 0x111 /* row_shr:1 */ : 0x138 /* wave_shr:1 */;
+            const uint32_t pl = (X & 16) ? ent[q] ^ ph_out[q] : __builtin_amdgcn_update_dpp(ent[q], ph_out[q], SHR, 0xF, 0xF, false);
+            const uint32_t ml = (X & 16) ? ent[2 + q] ^ mh_out[q] : __builtin_amdgcn_update_dpp(ent[2 + q], mh_out[q], SHR, 0xF, 0xF, false);
+            const bool active = in_range && (!CHECK || (s - lane) * R + q < nrows);
+            if (active) {
+                uint32_t Eq = eq_cur[q];
+                const uint32_t Xv = Eq | Mv;
+                Eq |= ml >> 31;
+                const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                const uint32_t Ph = Mv | ~(Xh | Pv);
+                const uint32_t Mh = Pv & Xh;
+                ph_out[q] = Ph;
+                mh_out[q] = Mh;
+                const uint32_t Phs = __builtin_amdgcn_alignbit(Ph, pl, 31);
+                const uint32_t Mhs = __builtin_amdgcn_alignbit(Mh, ml, 31);
+                Pv = Mhs | ~(Xv | Phs);
+                Mv = Phs & Xv;
+            }
+            // The band's right edge: every lane keeps the top bit of its Ph / Mh words of the last 32 rows (one v_alignbit each:
+            // acc << 1 | word >> 31); the band's last lane's are the edge, and only every 32 rows they go to LDS.  (LDS stores of
+            // the words themselves -- ds_write2_b32 or two ds_write_addtid_b32 per row -- cost this lone wave 22 cycles a row.)
+            if constexpr (!(X & 1)) {
+                if constexpr (NARROW) {
+                    acc_p = __builtin_amdgcn_alignbit(acc_p, ph_out[q] << edge_up, 31);
+                    acc_m = __builtin_amdgcn_alignbit(acc_m, mh_out[q] << edge_up, 31);
+                } else {
+                    acc_p = __builtin_amdgcn_alignbit(acc_p, ph_out[q], 31);
+                    acc_m = __builtin_amdgcn_alignbit(acc_m, mh_out[q], 31);
+                }
+            }
+        }
+        constexpr bool FLUSH = !(X & 1) && !CHECK && (JC + 1) * R % 32 == 0; // (a group of checked steps writes its chunks itself)
+        if constexpr (FLUSH)
+            asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4"
+                         :
+                         : "v"(out_addr), "v"(acc_p), "v"(acc_m), "n"(((JC + 1) * R / 32 - 1) * 128), "n"(((JC + 1) * R / 32 - 1) * 128 + 1)
+                         : "memory");
+        settle(eq_next, ent_far, chars_far, std::integral_constant<uint32_t, FLUSH ? 1 : 0>{});
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) eq_cur[q] = eq_next[q];
+        ent = ent_far;
+        chars_nxt = chars_far;
+    };
+
+#ifdef BMX_EXPERIMENTS
+    // cycle counts of the band in the middle of the forward pipeline (bmx_exp_ed_stamps)
+    const bool stamped = a.stamps != nullptr && blockIdx.x == a.bands / 2;
+    uint64_t st_groups = 0, st_steps = 0, st_between = 0, st_wait = 0;
+    const uint64_t st_begin = stamped ? __builtin_amdgcn_s_memtime() : 0;
+    uint64_t st_mark = st_begin;
+#endif
+    uint32_t have_fed = 0, have_handed = 0; // the helper's counters as last read
+    bool failed = false;
+    // Before group g: batch g + 1 fed (entries up to g G + G + 1), and the slot of my outgoing ring that group g - 4 filled handed
+    // over.  The helper runs up to seven batches ahead and hands a group over while I step the next: the counters as last read
+    // usually suffice, and the LDS round trip of reading them again is paid every few groups (band 0, which waits for nobody).
+    auto admit = [&](uint32_t g) {
+        if (have_fed >= g + 2 && have_handed + 3 >= g) return;
+#ifdef BMX_EXPERIMENTS
+        const uint64_t st_v0 = stamped ? __builtin_amdgcn_s_memtime() : 0;
+#endif
+        uint32_t polls = 0;
+        for (;;) {
+            const ed_u32x4 fl = flags_read4();
+            have_fed = __builtin_amdgcn_readfirstlane(fl.x);
+            have_handed = __builtin_amdgcn_readfirstlane(fl.z);
+            failed = __builtin_amdgcn_readfirstlane(fl.w) != 0;
+            if (failed || (have_fed >= g + 2 && have_handed + 3 >= g)) break;
+            if ((++polls & 255u) == 0 && hopeless()) {
+                give_up();
+                failed = true;
+                break;
+            }
+        }
+#ifdef BMX_EXPERIMENTS
+        if (stamped) st_wait += __builtin_amdgcn_s_memtime() - st_v0;
+#endif
+    };
+    auto aim = [&](uint32_t g) { // the rings' addresses for group g
+        const uint32_t s0 = g * G;
+        feed_addr = feed_base + (s0 & (FEED - 1)) * 16u;                        // entry s0
+        chars_addr = crng_base + ((s0 + 2u - lane) & (ED_BITS3_CHARS - 1)) * 4u; // entry s0 + 2 - lane
+        out_addr = out_base + (g & 3u) * (OUT_HALF * 4u);
+    };
+    // groups in which not every lane has a whole entry in every step: the first ceil(63 / G), and the last ones
+    auto checked_group = [&](uint32_t g) {
+        const uint32_t s0 = g * G;
+        admit(g);
+        if (failed) return;
+        if (g == 0) { // entries 0 and 1 are there
+            asm volatile("ds_read_b128 %0, %1" : "=v"(ent) : "v"(feed_base) : "memory");
+            uint32_t c0;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(c0) : "v"(crng_base + ((0u - lane) & (ED_BITS3_CHARS - 1)) * 4u) : "memory");
+            asm volatile("ds_read_b32 %0, %1" : "=v"(chars_nxt) : "v"(crng_base + ((1u - lane) & (ED_BITS3_CHARS - 1)) * 4u) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent), "+v"(c0), "+v"(chars_nxt)::"memory");
+            eq_request(eq_cur, c0);
+            uint32_t none = 0u;
+            settle(eq_cur, ent, none, std::integral_constant<uint32_t, 0>{});
+        }
+        aim(g);
+        const uint32_t n = steps - s0 < G ? steps - s0 : G;
+        for (uint32_t j = 0; j < n; ++j) {
+            step(s0 + j, std::true_type{}, std::integral_constant<uint32_t, 0>{}, std::true_type{});
+            feed_addr += 16u;
+            chars_addr += 4u;
+            const uint32_t rows_done = (j + 1) * R;
+            if ((rows_done & 31u) == 0 || j + 1 == n) { // a chunk of the edge is complete, or the band's steps are
+                const uint32_t up = (32u - (rows_done & 31u)) & 31u; // (an incomplete chunk: its first row to bit 31)
+                const uint32_t wp = acc_p << up, wm = acc_m << up;
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(out_addr + ((rows_done - 1) / 32) * 512u), "v"(wp), "v"(wm) : "memory");
+            }
+        }
+        flag_write(1, g + 1); // behind the group's writes to the outgoing ring
+    };
+    auto steady = [&](uint32_t g) { return g * G >= 63 && (g * G + G) * R <= nrows; }; // every lane a whole entry in each step
+    auto steady_groups = [&](uint32_t &g, auto narrow_tag) {
+        for (; g < ngroups && steady(g) && !failed; ++g) {
+            admit(g);
+            if (failed) break;
+            aim(g);
+#ifdef BMX_EXPERIMENTS
+            uint64_t st_t0 = 0;
+            if (stamped) {
+                st_t0 = __builtin_amdgcn_s_memtime();
+                st_between += st_t0 - st_mark;
+            }
+#endif
+            ed_unrolled<0, G>([&](auto jc) { step(g * G + decltype(jc)::value, std::false_type{}, jc, narrow_tag); });
+#ifdef BMX_EXPERIMENTS
+            if (stamped) {
+                st_mark = __builtin_amdgcn_s_memtime();
+                st_steps += st_mark - st_t0;
+                ++st_groups;
+            }
+#endif
+            flag_write(1, g + 1);
+        }
+    };
+    uint32_t g = 0;
+    for (; g < ngroups && !steady(g) && !failed; ++g) checked_group(g);
+#ifdef BMX_EXPERIMENTS
+    if (stamped) st_mark = __builtin_amdgcn_s_memtime();
+#endif
+    if (out_bit == 31)
+        steady_groups(g, std::false_type{});
+    else
+        steady_groups(g, std::true_type{});
+    for (; g < ngroups && !failed; ++g) checked_group(g);
+    if (failed) return;
+#ifdef BMX_EXPERIMENTS
+    if (stamped && lane == 0) {
+        a.stamps[0] = st_groups;
+        a.stamps[1] = st_steps;
+        a.stamps[2] = st_between;
+        a.stamps[3] = __builtin_amdgcn_s_memtime() - st_begin;
+        a.stamps[4] = st_wait;
+        a.stamps[5] = G;
+        a.stamps[6] = R;
+        a.stamps[7] = nent;
+    }
+#endif
+
+    // values on the cut row: vertex (nrows, 0) came in from the left; along the row a column adds (+1, 0, -1) - 1 to F
+    uint32_t *srow = a.stair_row[dir] + (uint64_t)J * (W + 1);
+    uint64_t ce = __hip_atomic_load(prev_rc + phys_r(nrows), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t polls = 0; (uint32_t)(ce >> 32) != a.tag; ) { // (handed over long ago: the helper has read rows beyond it)
+        if ((++polls & 255u) == 0 && hopeless()) {
+            give_up();
+            return;
+        }
+        ce = __hip_atomic_load(prev_rc + phys_r(nrows), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const uint32_t corner = (uint32_t)ce;
+    const uint32_t mine = (uint32_t)__popc(Pv) - (uint32_t)__popc(Mv) - 32u;
+    uint32_t f = corner + ed_wave_inclusive_scan(mine) - mine; // my LEFT edge
+    if (lane == 0) srow[phys_c(0) - col0] = corner;
+    for (uint32_t k = 0; k < 32; ++k) {
+        const uint32_t cc = lane * 32 + k;
+        f += ((Pv >> k) & 1u) - ((Mv >> k) & 1u) - 1u; // one column to the right on the same row
+        if (cc < ncols) srow[phys_c(cc + 1) - col0] = f;
+    }
+}
+
+} // namespace bmx
+
+#pragma clang diagnostic pop

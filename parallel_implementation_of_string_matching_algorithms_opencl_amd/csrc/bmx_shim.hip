@@ -25,6 +25,7 @@
 #include "bmx_ed_band_kernel.h"
 #include "bmx_ed_bits_kernel.h"
 #include "bmx_ed_bits2_kernel.h"
+#include "bmx_ed_bits3_kernel.h"
 #include "bmx_ed_kernel.h"
 #ifdef BMX_EXPERIMENTS
 #include "bmx_scan_ring_kernel.h"
@@ -176,6 +177,7 @@ struct bmx_ctx {
     int ed_lag = 0;              // >= 0 with ed_lag_set: rows a band is assumed to trail its predecessor by
     bool ed_lag_set = false;
     int ed_group = 32;           // hand-over group of the band pipeline (16 or 32 rows)
+    int ed_step_x = 0;           // libbmx_exp.so: timing experiment on the helper-wave band's step (index into g_ed_step_experiments)
     int sa_flags = 0;            // suffix array: 1 = library rounds only, 2 = a host wait per round, 4 = per-round trace on stderr
     const void *last_text = nullptr; // the text of the search whose status is awaited (its order_kernel samples it again)
     uint64_t last_text_n = 0;
@@ -1091,6 +1093,7 @@ struct EdVariant {
     uint32_t band_lds = 0;                 // dynamic LDS of the band kernel (the bit-parallel band's Eq table)
     int band_lag = 180;                    // rows a band trails its predecessor by (measured; places the cut rows)
     double step_cost = 0.0;                // instructions per row step, for the choice of the band (0: 25 + 3 band_c)
+    int band_threads = 64;                 // threads of a band's workgroup (128: a main and a helper wave)
 };
 #define BMX_ED(C_, R_, BC_)                                                                                     \
     {C_, R_, bmx::ed_tile_kernel<C_, R_, true>, bmx::ed_dual_kernel<C_, R_>, BC_, bmx::ed_band_kernel<BC_, 32>, \
@@ -1122,7 +1125,17 @@ const EdVariant g_ed_variants[] = {
      bmx::ed_bits2_lds(32, 2), 380, 20.5},
     {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits2_kernel<32, 1>, bmx::ed_bits2_kernel<16, 1>,
      bmx::ed_bits2_lds(32, 1), 190, 25.0},
+    // 13: ... with a helper wave per band that talks to the neighbouring bands (bmx_ed_bits3_kernel.h): groups of 32 / 16 steps
+    {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits3_kernel<32, 2>, bmx::ed_bits3_kernel<16, 2>,
+     bmx::ed_bits3_lds(32, 2), 480, 16.0, 128},
 };
+#ifdef BMX_EXPERIMENTS
+void (*const g_ed_step_experiments[])(const bmx::EdBandArgs) = {
+    bmx::ed_bits3_kernel<32, 2, 0>,  bmx::ed_bits3_kernel<32, 2, 1>,  bmx::ed_bits3_kernel<32, 2, 2>,  bmx::ed_bits3_kernel<32, 2, 4>,
+    bmx::ed_bits3_kernel<32, 2, 8>,  bmx::ed_bits3_kernel<32, 2, 16>, bmx::ed_bits3_kernel<32, 2, 3>,  bmx::ed_bits3_kernel<32, 2, 11>,
+    bmx::ed_bits3_kernel<32, 2, 27>,
+};
+#endif
 constexpr int N_ED_VARIANTS = sizeof(g_ed_variants) / sizeof(g_ed_variants[0]);
 constexpr int ED_ONE_DIRECTION = 16; // flag on the variant number: tiles, from the top-left corner only
 constexpr int ED_TILES = 32;         // flag: tiles from both corners (one launch per pair of tile diagonals)
@@ -1208,10 +1221,14 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
-        const auto kern = ctx->ed_group == 16 ? v.band16 : v.band;
+        auto kern = ctx->ed_group == 16 ? v.band16 : v.band;
+#ifdef BMX_EXPERIMENTS
+        if (ctx->ed_step_x > 0 && v.band_threads == 128 && ctx->ed_step_x < (int)(sizeof g_ed_step_experiments / sizeof g_ed_step_experiments[0]))
+            kern = g_ed_step_experiments[ctx->ed_step_x];
+#endif
         if (v.band_lds > 64 * 1024) e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.band_lds);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(kern, dim3(2 * bands), dim3(64), v.band_lds, stream, a);
+            hipLaunchKernelGGL(kern, dim3(2 * bands), dim3(v.band_threads), v.band_lds, stream, a);
             e = hipGetLastError();
         }
     }
@@ -1579,6 +1596,7 @@ int bmx_exp_set_knob(bmx_ctx *ctx, const char *name, int value)
     else if (k == "multi_no_qgram") ctx->multi_no_qgram = value != 0;
     else if (k == "ed_lag") ctx->ed_lag = value, ctx->ed_lag_set = value >= 0;
     else if (k == "ed_group") ctx->ed_group = value;
+    else if (k == "ed_step_x") ctx->ed_step_x = value;
     else if (k == "sa_flags") ctx->sa_flags = value;
     else return BMX_ERR_ARG;
     return BMX_OK;

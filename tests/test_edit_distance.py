@@ -71,10 +71,10 @@ def test_gpu_vs_oracle_around_tile_edges_all_tile_shapes(ctx, port):
         # 0: the library's own choice; 1..7: columns per lane (band pipeline, one launch); 8 / 9 / 10: the bit-parallel band (2048
         # columns per wave) with one / two / four rows per step; +32: tiles filled from both corners at once where there are three tile diagonals or more; +16:
         # tiles from the top-left corner only
-        for v in [0, 8, 9, 10, 11, 12, 2, 4, 7, 5, 32, 33, 34, 35, 16, 17, 18, 20]:
+        for v in [0, 8, 9, 10, 11, 12, 13, 2, 4, 7, 5, 32, 33, 34, 35, 16, 17, 18, 20]:
             ctx.set_ed_variant(v)
-            for it in range(14 if v not in (8, 9, 10, 11, 12) else 40):
-                ls = lens if v not in (8, 9, 10, 11, 12) else lens + [3, 4, 5, 31, 32, 33, 2016, 2047, 2048, 2049, 2080, 4095, 4097, 6200]
+            for it in range(14 if v not in (8, 9, 10, 11, 12, 13) else 40):
+                ls = lens if v not in (8, 9, 10, 11, 12, 13) else lens + [3, 4, 5, 31, 32, 33, 2016, 2047, 2048, 2049, 2080, 4095, 4097, 6200]
                 la, lb = int(rng.choice(ls)), int(rng.choice(ls))
                 al = int(rng.integers(2, 5))
                 x = (rng.integers(0, al, la) + 97).astype(np.uint8)
@@ -122,17 +122,20 @@ def test_gpu_band_pipeline_cut_shapes(exp_ctx, port):
     shapes = [(1, 1), (70, 300), (300, 70), (257, 256), (256, 257), (1000, 1500), (1500, 1000), (3000, 513),
               (513, 3000), (2048, 2048)]
     shapes = shapes + [(5000, 900), (900, 5000), (4096, 4096), (6500, 2049)]  # (several bands of the bit-parallel kernel: 2048 columns each)
-    for lag, variant in [(l, v) for v in (0, 4, 8, 9, 10, 11, 12) for l in ("0", "3", "64", "200", "700", "100000")]:
+    for lag, variant in [(l, v) for v in (0, 4, 8, 9, 10, 11, 12, 13) for l in ("0", "3", "64", "200", "700", "100000")]:
         exp_ctx.set_knob("ed_lag", int(lag))  # (a switch of libbmx_exp.so: the product library assumes its measured lag)
         exp_ctx.set_ed_variant(variant)       # (0: the library's choice; 4: bands of 384 columns; 8 / 9 / 10: bit-parallel bands, 1 / 2 / 4 rows per step)
         ctx = exp_ctx
-        for la, lb in shapes:
-            x = (rng.integers(0, 3, la) + 97).astype(np.uint8)
-            y = (rng.integers(0, 3, lb) + 97).astype(np.uint8)
-            if la == lb:
-                y = x.copy()
-                y[rng.integers(0, la, la // 7 + 1)] = ord("q")
-            assert ctx.edit_distance(x, y) == port.edit_distance(x, y), (lag, la, lb)
+        for grp in ((32, 16) if variant >= 11 else (32,)):  # (the other hand-over group: another kernel instance of these)
+            exp_ctx.set_knob("ed_group", grp)
+            for la, lb in shapes:
+                x = (rng.integers(0, 3, la) + 97).astype(np.uint8)
+                y = (rng.integers(0, 3, lb) + 97).astype(np.uint8)
+                if la == lb:
+                    y = x.copy()
+                    y[rng.integers(0, la, la // 7 + 1)] = ord("q")
+                assert ctx.edit_distance(x, y) == port.edit_distance(x, y), (lag, variant, grp, la, lb)
+        exp_ctx.set_knob("ed_group", 32)
 
 
 @pytest.mark.gpu
@@ -179,7 +182,7 @@ def test_gpu_config5_64k_properties(ctx, port):
     d1 = ctx.edit_distance_device(dx, dz)
     assert d1 == ctx.edit_distance_device(dz, dx)
     try:
-        for v in (16, 32, 4, 8, 9, 10, 11, 12):  # tiles from one corner (the first schedule) / from both corners; value bands; bit-parallel bands
+        for v in (16, 32, 4, 8, 9, 10, 11, 12, 13):  # tiles from one corner (the first schedule) / from both corners; value bands; bit-parallel bands
             ctx.set_ed_variant(v)
             assert d1 == ctx.edit_distance_device(dx, dz)
     finally:

@@ -8,7 +8,7 @@ rng = np.random.default_rng(5)
 x = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 z = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 ctx = host.Context(0, library=host.exp_lib())  # the lag / group switches exist in libbmx_exp.so only
-sel = [tuple(int(t) for t in a.split(':')) for a in sys.argv[2:]] or [(11, 32), (11, 16), (12, 32), (12, 16), (9, 32), (4, 32)]
+sel = [tuple(int(t) for t in a.split(':')) for a in sys.argv[2:]] or [(13, 32), (13, 16), (11, 32), (9, 32)]
 for v, grp in sel:
     ctx.set_ed_variant(v)
     ctx.set_knob("ed_group", grp)
@@ -21,7 +21,7 @@ for v, grp in sel:
             ms.append(ctx.last_edit_distance_ms())
         row[lag] = round(min(ms[1:]), 3)
     out = {"variant": v, "group": grp, "distance": d, "ms_by_lag": row}
-    if v in (11, 12):  # where the middle band's cycles went, at the default lag
+    if v in (11, 12, 13):  # where the middle band's cycles went, at the default lag
         ctx.set_knob("ed_lag", -1)
         ctx.edit_distance_device(x, z)
         st = ctx.ed_stamps()
