@@ -70,6 +70,7 @@ struct EdBandArgs {
     uint32_t tag;           // != 0
     uint64_t timeout_ticks;
     uint64_t *stamps;       // libbmx_exp.so: 8 words of cycle counts of ONE band (bmx_exp_ed_stamps); nullptr otherwise
+    uint32_t stamp_block;   // ... of the band with this block index
 };
 
 __device__ __forceinline__ uint64_t ed_entry(uint32_t value, uint32_t tag) { return ((uint64_t)tag << 32) | value; }

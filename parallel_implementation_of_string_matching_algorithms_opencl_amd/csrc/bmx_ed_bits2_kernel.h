@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) void ed_bits2_kernel(const EdBandArgs a)
 #ifdef BMX_EXPERIMENTS
     // cycle counts of the band in the middle of the forward pipeline: [groups of unrolled steps, cycles in them, cycles between them
     // (validate / ring / hand-over / request), cycles of the whole loop, of which waiting for the band in front]
-    const bool stamped = a.stamps != nullptr && blockIdx.x == a.bands / 2;
+    const bool stamped = a.stamps != nullptr && blockIdx.x == a.stamp_block;
     uint64_t st_groups = 0, st_steps = 0, st_between = 0, st_wait = 0, st_mark = 0;
     const uint64_t st_begin = stamped ? __builtin_amdgcn_s_memtime() : 0;
     st_mark = st_begin;

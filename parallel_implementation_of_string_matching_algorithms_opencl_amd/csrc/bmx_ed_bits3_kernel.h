@@ -1,23 +1,35 @@
-// bmx_ed_bits3_kernel.h -- Levenshtein distance: the bit-parallel band of bmx_ed_bits2_kernel.h with a HELPER wave.
+// bmx_ed_bits3_kernel.h -- Levenshtein distance: the bit-parallel band of bmx_ed_bits2_kernel.h as a workgroup of FOUR waves.
 //
-// Cycle counts of one band of ed_bits2_kernel<32, 2> (bmx_exp_ed_stamps, profiles/r03_ed_lag_sweep_bits2_stamps.jsonl): 227 per
-// step of two rows, and 1,760 BETWEEN two groups of 32 steps -- validating the next group of the band in front, turning it into
-// edge bits, handing the own edge over (LDS round trips, a prefix sum, 64-bit addresses, HBM stores) -- a fifth of the time, on the
-// one wave whose dependent chain IS the critical path.  And the look-ahead of those groups (2 G entries requested, G handed over
-// at a time) is what keeps a band ~190 steps behind the one in front where the systolic skew alone would be 63.
+// The band pipeline's time is the time of ONE wave's dependent chain: (rows / R + bands * lag) steps of band 0's main wave.  Cycle
+// counts of one band of ed_bits2_kernel<32, 2> (bmx_exp_ed_stamps, profiles/r03_ed_lag_sweep_bits2_stamps.jsonl): 227 per step of
+// two rows and 1,760 BETWEEN two groups of 32 steps -- validating the next group of the band in front, turning it into edge bits,
+// handing the own edge over (LDS round trips, a prefix sum, 64-bit addresses, HBM stores): a fifth of the time on the wave that
+// is the critical path.  What a lone wave pays per instruction was measured (tools/probes/valu_issue_probe.hip,
+// profiles/r03_lone_wave_issue_costs.jsonl: plain VALU 4.0 cycles dependent or not, v_alignbit 4.3-4.8, DPP wave_shr 4.6, an LDS
+// store 11-22) and so was the step with parts left out (tools/ed_step_experiments.py): the recurrence is 142 cycles, everything
+// else had to go to other waves -- a CU has four SIMDs and a band used one.
 //
-// Here a band is a workgroup of TWO waves on two SIMDs of a CU:
-//   wave 0 (main)    only steps: per step one ring entry with the band edge's bits (ds_read_b128), its characters two steps ahead
-//                    (ds_read_b32 from a ring of characters: lane l reads entry s + 2 - l, so the characters need no DPP chain
-//                    either), the Eq words a step ahead, R rows of the recurrence, its Ph / Mh words into the outgoing ring.
-//                    Per group of G steps: two LDS flag words checked (cached: read again only when they do not suffice), one written.
-//   wave 1 (helper)  polls the band in front (HBM entries {F, tag}), turns a batch of G entries into ring entries, and hands the
-//                    main wave's finished groups over (edge bit -> differences -> prefix sum -> {F, tag} to HBM), whichever is
-//                    possible; never blocks on one while the other is due.
-// Between them, in LDS: feed ring (4 G entries of {P0, P1, M0, M1} + one mirrored), character ring (256 entries + G mirrored), the
-// outgoing ring per lane (two groups deep), and three counters: batches fed, groups stepped, groups handed over.  LDS instructions
-// of a wave complete in order, so "data, then counter" needs no wait on the writer's side beyond what orders its own instructions.
+//   wave 0 (main)       only steps.  Per step of R = 2 rows, 36 instructions: the feed-ring entry of the next step (ds_read_b128:
+//                       the band edge's bits for lane 0), the Eq words of the next step (ONE ds_read_b64, same slot for all lanes,
+//                       immediate offset), the recurrence with the hand to the right as raw Ph / Mh words (DPP move +
+//                       v_alignbit), and the band's right edge collected as the top bit of every lane's Ph / Mh per row (one
+//                       v_alignbit each) and written to LDS every 32 rows.  Groups of G steps are unrolled; per group two
+//                       counters of the other waves are compared with their last read values (read again only when those do not
+//                       suffice) and one is written.
+//   wave 1 (feeder)     polls the band in front (HBM entries {F, tag}), turns a batch of G entries into feed-ring entries (edge
+//                       bits at bit 31, where v_alignbit looks) and character-ring entries (row characters << 8).
+//   wave 2 (Eq words)   lane l's Eq words of step t = Eq table [characters of entry t - l][l] -> Eq-word ring [step][lane]; runs
+//                       as far ahead as characters are fed and the ring has room.  (On the main wave this was a character
+//                       request, two SDWA adds and two LDS requests per step: 36 cycles of 203.)
+//   wave 3 (publisher)  hands the main wave's finished groups over: edge bits -> differences -> one prefix sum -> {F, tag} to HBM.
+//                       Apart from the feeder, which waits up to a memory round trip for a batch it has requested.
+// Between them, in LDS: feed ring (8 G entries of {P0, P1, M0, M1} + one mirrored: a group's last step reads one entry on),
+// character ring (512), Eq-word ring (4 G steps x 64 lanes x 2 words + one mirrored), outgoing ring (4 groups x [chunk of 32
+// rows][lane][+1 bits | -1 bits]) and five counters (steps with Eq words, groups stepped, groups handed over, failed, batches
+// fed).  LDS instructions of a wave complete in order, so "data, then counter" needs no wait on the writer's side.  Batches end
+// where the groups of the band in front end (entries up to k G with its group k + 1): a batch is complete with ONE group.
 // What goes to HBM is what went there before ({F, tag} per row): the value bands, the meet kernel and the cut rows do not change.
+// Measured (64k x 64k, profiles/r03_ed_*): 2.20 ms (bits2) -> 1.64 ms; per step 174 cycles, 390 between groups, lag 250 steps.
 //
 // Reference: EditDistance-1/EditDistance-1/kernal.cl:5-56 + EditDistance-1.cpp:278-345; recurrence as sequential.c:18-46.
 #pragma once
@@ -37,14 +49,14 @@ namespace bmx {
 constexpr uint32_t ED_BITS3_CHARS = 512; // entries of the character ring
 constexpr uint32_t ed_bits3_lds(uint32_t group, uint32_t rows)
 {
-    // Eq table | feed ring | character ring | counters | outgoing rings
-    return (ED_BITS2_PEQ_WORDS + (8 * group + 1) * 4 + (ED_BITS3_CHARS + group) + 8 + 4 * (group * rows / 32) * 128) * 4;
+    // Eq table | feed ring | character ring | counters | outgoing ring | Eq-word ring
+    return (ED_BITS2_PEQ_WORDS + (8 * group + 1) * 4 + (ED_BITS3_CHARS + group) + 8 + 4 * (group * rows / 32) * 128 + (4 * group + 1) * 128) * 4;
 }
 
-// X: timing experiments (libbmx_exp.so; the distance is then WRONG): 1 no writes to the outgoing ring, 2 no Eq requests, 4 row_shr
-// instead of wave_shr in the hand to the right, 8 no feed-ring / character-ring requests, 16 no hand to the right at all
+// X: timing experiments (libbmx_exp.so; the distance is then WRONG): 1 the band's right edge not collected, 2 no Eq-word requests,
+// 4 row_shr instead of wave_shr in the hand to the right, 8 no feed-ring requests, 16 no hand to the right at all
 template <int GROUP, int R, int X = 0>
-__global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
+__global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
 {
     static_assert(R == 1 || R == 2, "a feed-ring entry is four words: R <= 2 rows");
     static_assert((GROUP == 16 || GROUP == 32) && GROUP * R % 32 == 0, "a group is whole chunks of 32 rows of the outgoing edge");
@@ -57,11 +69,15 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
     uint32_t *const peq = ed_lds;                            // [256][64]
     uint32_t *const feed = peq + ED_BITS2_PEQ_WORDS;         // [FEED + 1] x {P0, P1, M0, M1}
     uint32_t *const crng = feed + (FEED + 1) * 4;            // [512 + G] characters of an entry: c0 << 8 | c1 << 24
-    uint32_t *const flags = crng + ED_BITS3_CHARS + G;       // [0] batches fed, [1] groups stepped, [2] groups handed over, [3] failed
+    uint32_t *const flags = crng + ED_BITS3_CHARS + G;       // [0] steps with Eq words, [1] groups stepped, [2] groups handed over,
+                                                             // [3] failed, [4] batches fed
     uint32_t *const outw = flags + 8;                        // [4][OUT_HALF]
+    constexpr uint32_t EQR = 4 * G;                          // steps of the Eq-word ring
+    uint32_t *const eqr = outw + 4 * OUT_HALF;               // [EQR + 1][64] x {Eq of row 0, Eq of row 1}
 
     const uint32_t lane = threadIdx.x & 63u;
-    const bool helper = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // 0 main, 1 feeder, 2 Eq words, 3 publisher
+    const bool helper = wave == 1 || wave == 3;
     const bool mirror = blockIdx.x >= a.bands;               // wave-uniform
     const uint32_t Jt = blockIdx.x - (mirror ? a.bands : 0); // band in pipeline order
     const uint32_t J = mirror ? a.bands - 1 - Jt : Jt;       // physical band
@@ -80,9 +96,9 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
     const uint32_t out_lane = (ncols - 1) / 32, out_bit = (ncols - 1) % 32; // the band's right edge
 
     // the Eq table: zeroed by both waves, then every lane of the main wave sets the bits of its 32 columns in its own column
-    for (uint32_t i = threadIdx.x; i < (uint32_t)(outw - ed_lds); i += 128) ed_lds[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(outw - ed_lds); i += 256) ed_lds[i] = 0u;
     __syncthreads();
-    if (!helper) {
+    if (wave == 0) {
         for (uint32_t k = 0; k < 32; ++k) {
             const uint32_t cc = lane * 32 + k;
             if (cc < ncols) {
@@ -94,7 +110,7 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
     }
     __syncthreads();
     if (steps == 0) { // no rows on my side of the cut: the cut row is the table's edge row
-        if (!helper) {
+        if (wave == 0) {
             uint32_t *srow = a.stair_row[dir] + (uint64_t)J * (W + 1);
             for (uint32_t cc = lane; cc <= ncols; cc += 64) srow[phys_c(cc) - col0] = 0u;
         }
@@ -127,14 +143,15 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
             return rr < nrows ? rr : nrows - 1; // (clamped: a row past the end is never consumed)
         };
         auto char_at = [&](uint32_t rr) { return a.b[mirror ? a.lb - 1 - rr : rr]; };
-        // batch k = entries (k - 1) G + 2 ... k G + 1: what the main wave reads up to the last step of group k - 1
-        // (batch 0 = entries 0 and 1, in the last two lanes; lane i of the first G holds entry (k - 1) G + 2 + i)
+        // batch k = entries (k - 1) G + 1 ... k G: what the main wave needs up to the last step of group k - 1 (that step requests
+        // the feed-ring entry and the Eq words of the step behind it).  The band in front hands over entries up to (j + 1) G - 64
+        // with its group j: a batch is complete with ONE of its groups.  (Batch 0 = entry 0, in lane G - 1.)
         const uint32_t nbatches = ngroups + 1;
         struct Batch {
             uint64_t left[R];
             uint8_t b[R];
         };
-        auto entry_of = [&](uint32_t k) { return (k - 1u) * G + 2u + (lane & (G - 1)); }; // (wraps below 0 in batch 0)
+        auto entry_of = [&](uint32_t k) { return (k - 1u) * G + 1u + (lane & (G - 1)); }; // (wraps below 0 in batch 0)
         auto load_batch = [&](uint32_t k) {
             Batch g;
             uint32_t e = entry_of(k);
@@ -202,7 +219,10 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
             edge_f += __builtin_amdgcn_readlane(incl, 63);
         };
 
-        uint32_t fed = 0, handed = 0, polls = 0;
+        // two waves run this: the feeder (wave 1) only feeds, the publisher (wave 3) only hands over -- the feeder waits up to a
+        // memory round trip for a batch it has requested, and the band behind must not wait for that
+        const bool feeds = wave == 1;
+        uint32_t fed = feeds ? 0u : nbatches, handed = feeds ? ngroups : 0u, polls = 0;
         Batch nxt = load_batch(0);
         bool requested = true;
         while (fed < nbatches || handed < ngroups) {
@@ -228,7 +248,7 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
                 if (__ballot(bad) == 0) {
                     to_rings(nxt, fed);
                     ++fed;
-                    flag_write(0, fed);
+                    flag_write(4, fed);
                     progress = true;
                     if (fed < nbatches) nxt = load_batch(fed);
                     else requested = false;
@@ -247,51 +267,89 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
         return;
     }
 
+    if (wave == 2) {
+        // ---------------------------------------------------------------- Eq-word wave
+        // Lane l's Eq words of step t = the columns of lane l that equal the characters of entry t - l: character ring -> Eq table
+        // -> Eq-word ring [step][lane], which the main wave reads with ONE instruction per step (same slot for all its lanes, no
+        // address arithmetic) where it spent five (character request, two SDWA adds, two Eq requests: 25 + 11 cycles of its 203).
+        // Runs as far ahead as the characters are fed and the ring has room.
+        uint32_t t = 0, polls = 0;
+        while (t <= steps) { // (the main wave's last step still requests the slot of the step behind it)
+            const ed_u32x4 fl = flags_read4();
+            if (__builtin_amdgcn_readfirstlane(fl.w) != 0) return;
+            const uint32_t stepped = __builtin_amdgcn_readfirstlane(fl.y);
+            uint32_t fed;
+            asm volatile("ds_read_b32 %0, %1 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=v"(fed) : "v"(flags_addr) : "memory");
+            fed = __builtin_amdgcn_readfirstlane(fed);
+            // lane 0 needs entry t: batches 0 .. fed - 1 hold the entries up to (fed - 1) G; slot t is free once the main wave
+            // has finished step t - EQR - 1 (it reads a step's slot in the step before)
+            uint32_t hi = fed ? (fed - 1u) * G + 1u : 0u;
+            hi = hi < stepped * G + EQR + 1u ? hi : stepped * G + EQR + 1u;
+            hi = hi < steps + 1u ? hi : steps + 1u;
+            if (t >= hi) {
+                if ((++polls & 255u) == 0 && hopeless()) {
+                    give_up();
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            auto eq_word = [&](uint32_t chars, uint32_t q) {
+                return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(peq) + ((chars >> (16 * q)) & 0xffffu) + lane * 4u);
+            };
+            auto put = [&](uint32_t tt, uint32_t e0, uint32_t e1) {
+                const uint32_t slot = tt & (EQR - 1);
+                uint2 *dst = reinterpret_cast<uint2 *>(eqr) + slot * 64 + lane;
+                *dst = make_uint2(e0, e1);
+                if (slot == 0) dst[EQR * 64] = make_uint2(e0, e1); // a group's last step reads one slot on
+            };
+            for (; t + 4 <= hi; t += 4) { // four steps' requests in flight together
+                uint32_t ch[4], eq[4][2];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) ch[i] = crng[(t + i - lane) & (ED_BITS3_CHARS - 1)];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                    eq[i][0] = eq_word(ch[i], 0);
+                    eq[i][1] = R > 1 ? eq_word(ch[i], 1) : 0u;
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) put(t + i, eq[i][0], eq[i][1]);
+            }
+            for (; t < hi; ++t) {
+                const uint32_t chars = crng[(t - lane) & (ED_BITS3_CHARS - 1)];
+                put(t, eq_word(chars, 0), R > 1 ? eq_word(chars, 1) : 0u);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            flag_write(0, t);
+        }
+        return;
+    }
+
     // -------------------------------------------------------------------- main wave
     uint32_t Pv = ~0u, Mv = 0u;    // row 0: D[0][c] = c
     uint32_t ph_out[R], mh_out[R]; // what my columns handed to the right in my previous step
     uint32_t eq_cur[R];
 #pragma unroll
     for (uint32_t q = 0; q < R; ++q) ph_out[q] = mh_out[q] = eq_cur[q] = 0u;
-    uint32_t chars_nxt = 0u;     // before step s: the characters of entry s + 1 - lane (my next step's)
     ed_u32x4 ent = {0, 0, 0, 0}; // before step s: feed-ring entry s (the band edge's bits for lane 0)
-    const uint32_t lane_off = (uint32_t)(uintptr_t)peq + lane * 4u;
     const uint32_t feed_base = (uint32_t)(uintptr_t)feed;
-    const uint32_t crng_base = (uint32_t)(uintptr_t)crng;
+    const uint32_t eqr_base = (uint32_t)(uintptr_t)eqr + lane * 8u;
     const uint32_t out_base = (uint32_t)(uintptr_t)outw + lane * 8u;
-    uint32_t feed_addr = feed_base, chars_addr = crng_base, out_addr = out_base;
+    uint32_t feed_addr = feed_base, eq_addr = eqr_base, out_addr = out_base;
     uint32_t acc_p = 0u, acc_m = 0u; // the band-edge bit of my Ph / Mh words of the last 32 rows, oldest row on top
     const uint32_t edge_up = 31u - out_bit; // (the narrow band's edge bit is not bit 31: moved there first)
 
-    auto eq_request = [&](uint32_t (&dst)[R], uint32_t chars) {
-#pragma unroll
-        for (uint32_t q = 0; q < R; ++q) {
-            uint32_t addr;
-            if (q == 0)
-                asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD"
-                             : "=v"(addr)
-                             : "v"(chars), "v"(lane_off));
-            else
-                asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
-                             : "=v"(addr)
-                             : "v"(chars), "v"(lane_off));
-            asm volatile("ds_read_b32 %0, %1" : "=v"(dst[q]) : "v"(addr) : "memory");
-        }
-    };
+    typedef uint32_t ed_u32x2 __attribute__((ext_vector_type(2)));
     // (LDS words requested by inline asm have landed behind this wait: the values pass THROUGH it, or hipcc schedules their use in
     // front of it.)  BEHIND = LDS instructions issued after the requests that need not be waited for (in-order completion): the
     // write of a chunk of the outgoing edge comes last in its step.
-    auto settle = [&](uint32_t (&w)[R], ed_u32x4 &e, uint32_t &c, auto behind) {
+    auto settle = [&](ed_u32x2 &w, ed_u32x4 &e, auto behind) {
         constexpr uint32_t BEHIND = decltype(behind)::value;
         static_assert(BEHIND <= 1, "");
-        if constexpr (R == 1 && BEHIND == 0)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(e), "+v"(c)::"memory");
-        else if constexpr (R == 1)
-            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w[0]), "+v"(e), "+v"(c)::"memory");
-        else if constexpr (BEHIND == 0)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(e), "+v"(c)::"memory");
+        if constexpr (BEHIND == 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w), "+v"(e)::"memory");
         else
-            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w[0]), "+v"(w[1]), "+v"(e), "+v"(c)::"memory");
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w), "+v"(e)::"memory");
     };
 
     // One step: R rows of my 32 columns.  JC = the step's number within its group where the group is unrolled (ring addresses are
@@ -301,24 +359,20 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
         constexpr uint32_t JC = decltype(jc)::value;
         constexpr bool NARROW = decltype(narrow_tag)::value; // the band's last column is not bit 31 of a lane
         const bool in_range = !CHECK || (lane <= s && lane + nent > s);
-        uint32_t chars_far;
         ed_u32x4 ent_far;
+        ed_u32x2 eq_far;
         if constexpr (X & 8) {
-            chars_far = chars_nxt;
             ent_far = ent;
         } else {
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(chars_far) : "v"(chars_addr), "n"(JC * 4) : "memory");        // entry s + 2 - lane
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ent_far) : "v"(feed_addr), "n"((JC + 1) * 16) : "memory"); // entry s + 1
         }
-        uint32_t eq_next[R];
         if constexpr (X & 2) {
-#pragma unroll
-            for (uint32_t q = 0; q < R; ++q) eq_next[q] = eq_cur[q] ^ chars_nxt;
+            eq_far[0] = eq_cur[0] ^ ent[0];
+            eq_far[1] = eq_cur[R - 1] ^ ent[1];
         } else {
-            eq_request(eq_next, chars_nxt);
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(eq_far) : "v"(eq_addr), "n"((JC + 1) * 512) : "memory"); // step s + 1's
         }
-        // (the rows below start from Pv / Mv: passed through here, they cannot be scheduled in front of the requests -- hipcc moved
-        // the step's first row up there, and the step's wait then came ~40 cycles after the last request instead of ~130)
+        // (the rows below start from Pv / Mv: passed through here, they cannot be scheduled in front of the requests)
         asm volatile("" : "+v"(Pv), "+v"(Mv));
 #pragma unroll
         for (uint32_t q = 0; q < R; ++q) {
@@ -361,37 +415,38 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
                          :
                          : "v"(out_addr), "v"(acc_p), "v"(acc_m), "n"(((JC + 1) * R / 32 - 1) * 128), "n"(((JC + 1) * R / 32 - 1) * 128 + 1)
                          : "memory");
-        settle(eq_next, ent_far, chars_far, std::integral_constant<uint32_t, FLUSH ? 1 : 0>{});
+        settle(eq_far, ent_far, std::integral_constant<uint32_t, FLUSH ? 1 : 0>{});
 #pragma unroll
-        for (uint32_t q = 0; q < R; ++q) eq_cur[q] = eq_next[q];
+        for (uint32_t q = 0; q < R; ++q) eq_cur[q] = eq_far[q];
         ent = ent_far;
-        chars_nxt = chars_far;
     };
 
 #ifdef BMX_EXPERIMENTS
     // cycle counts of the band in the middle of the forward pipeline (bmx_exp_ed_stamps)
-    const bool stamped = a.stamps != nullptr && blockIdx.x == a.bands / 2;
+    const bool stamped = a.stamps != nullptr && blockIdx.x == a.stamp_block;
     uint64_t st_groups = 0, st_steps = 0, st_between = 0, st_wait = 0;
     const uint64_t st_begin = stamped ? __builtin_amdgcn_s_memtime() : 0;
     uint64_t st_mark = st_begin;
 #endif
-    uint32_t have_fed = 0, have_handed = 0; // the helper's counters as last read
+    uint32_t have_eq = 0, have_handed = 0; // the other waves' counters as last read
     bool failed = false;
-    // Before group g: batch g + 1 fed (entries up to g G + G + 1), and the slot of my outgoing ring that group g - 4 filled handed
-    // over.  The helper runs up to seven batches ahead and hands a group over while I step the next: the counters as last read
-    // usually suffice, and the LDS round trip of reading them again is paid every few groups (band 0, which waits for nobody).
+    // Before group g: the Eq words up to the step behind the group's last (which implies the feed ring's entries up to there: the Eq
+    // wave goes by the batches fed), and the slot of my outgoing ring that group g - 4 filled handed over.  The other waves run
+    // groups ahead: the counters as last read usually suffice, and the LDS round trip of reading them again is paid every few
+    // groups (band 0, which waits for nobody).
     auto admit = [&](uint32_t g) {
-        if (have_fed >= g + 2 && have_handed + 3 >= g) return;
+        const uint32_t need = g * G + G < steps ? g * G + G + 1 : steps + 1; // (the Eq wave stops behind the last step)
+        if (have_eq >= need && have_handed + 3 >= g) return;
 #ifdef BMX_EXPERIMENTS
         const uint64_t st_v0 = stamped ? __builtin_amdgcn_s_memtime() : 0;
 #endif
         uint32_t polls = 0;
         for (;;) {
             const ed_u32x4 fl = flags_read4();
-            have_fed = __builtin_amdgcn_readfirstlane(fl.x);
+            have_eq = __builtin_amdgcn_readfirstlane(fl.x);
             have_handed = __builtin_amdgcn_readfirstlane(fl.z);
             failed = __builtin_amdgcn_readfirstlane(fl.w) != 0;
-            if (failed || (have_fed >= g + 2 && have_handed + 3 >= g)) break;
+            if (failed || (have_eq >= need && have_handed + 3 >= g)) break;
             if ((++polls & 255u) == 0 && hopeless()) {
                 give_up();
                 failed = true;
@@ -405,7 +460,7 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
     auto aim = [&](uint32_t g) { // the rings' addresses for group g
         const uint32_t s0 = g * G;
         feed_addr = feed_base + (s0 & (FEED - 1)) * 16u;                        // entry s0
-        chars_addr = crng_base + ((s0 + 2u - lane) & (ED_BITS3_CHARS - 1)) * 4u; // entry s0 + 2 - lane
+        eq_addr = eqr_base + (s0 & (EQR - 1)) * 512u;                           // step s0
         out_addr = out_base + (g & 3u) * (OUT_HALF * 4u);
     };
     // groups in which not every lane has a whole entry in every step: the first ceil(63 / G), and the last ones
@@ -413,22 +468,20 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
         const uint32_t s0 = g * G;
         admit(g);
         if (failed) return;
-        if (g == 0) { // entries 0 and 1 are there
+        if (g == 0) { // entry 0 and step 0's Eq words are there
+            ed_u32x2 e0;
             asm volatile("ds_read_b128 %0, %1" : "=v"(ent) : "v"(feed_base) : "memory");
-            uint32_t c0;
-            asm volatile("ds_read_b32 %0, %1" : "=v"(c0) : "v"(crng_base + ((0u - lane) & (ED_BITS3_CHARS - 1)) * 4u) : "memory");
-            asm volatile("ds_read_b32 %0, %1" : "=v"(chars_nxt) : "v"(crng_base + ((1u - lane) & (ED_BITS3_CHARS - 1)) * 4u) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ent), "+v"(c0), "+v"(chars_nxt)::"memory");
-            eq_request(eq_cur, c0);
-            uint32_t none = 0u;
-            settle(eq_cur, ent, none, std::integral_constant<uint32_t, 0>{});
+            asm volatile("ds_read_b64 %0, %1" : "=v"(e0) : "v"(eqr_base) : "memory");
+            settle(e0, ent, std::integral_constant<uint32_t, 0>{});
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q) eq_cur[q] = e0[q];
         }
         aim(g);
         const uint32_t n = steps - s0 < G ? steps - s0 : G;
         for (uint32_t j = 0; j < n; ++j) {
             step(s0 + j, std::true_type{}, std::integral_constant<uint32_t, 0>{}, std::true_type{});
             feed_addr += 16u;
-            chars_addr += 4u;
+            eq_addr += 512u;
             const uint32_t rows_done = (j + 1) * R;
             if ((rows_done & 31u) == 0 || j + 1 == n) { // a chunk of the edge is complete, or the band's steps are
                 const uint32_t up = (32u - (rows_done & 31u)) & 31u; // (an incomplete chunk: its first row to bit 31)
@@ -438,11 +491,18 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
         }
         flag_write(1, g + 1); // behind the group's writes to the outgoing ring
     };
-    auto steady = [&](uint32_t g) { return g * G >= 63 && (g * G + G) * R <= nrows; }; // every lane a whole entry in each step
+    // every lane has a whole entry in each step of the groups [g_lo, g_hi): their steps need no checks and are unrolled
+    const uint32_t g_lo = (63 + G - 1) / G;
+    const uint32_t g_hi_raw = nrows / (G * R);
+    const uint32_t g_hi = g_hi_raw < ngroups ? g_hi_raw : ngroups;
+    // (one forward branch not taken, one backward branch taken per group: a taken branch costs this lone wave a refill of its
+    // instruction buffer, and the loop around the groups had six)
     auto steady_groups = [&](uint32_t &g, auto narrow_tag) {
-        for (; g < ngroups && steady(g) && !failed; ++g) {
-            admit(g);
-            if (failed) break;
+        do {
+            if (__builtin_expect(!(have_eq >= g * G + G + 1 && have_handed + 3 >= g), 0)) {
+                admit(g);
+                if (failed) return;
+            }
             aim(g);
 #ifdef BMX_EXPERIMENTS
             uint64_t st_t0 = 0;
@@ -459,18 +519,21 @@ __global__ __launch_bounds__(128) void ed_bits3_kernel(const EdBandArgs a)
                 ++st_groups;
             }
 #endif
-            flag_write(1, g + 1);
-        }
+            ++g;
+            flag_write(1, g);
+        } while (g < g_hi);
     };
     uint32_t g = 0;
-    for (; g < ngroups && !steady(g) && !failed; ++g) checked_group(g);
+    for (; g < ngroups && (g < g_lo || g >= g_hi) && !failed; ++g) checked_group(g);
 #ifdef BMX_EXPERIMENTS
     if (stamped) st_mark = __builtin_amdgcn_s_memtime();
 #endif
-    if (out_bit == 31)
-        steady_groups(g, std::false_type{});
-    else
-        steady_groups(g, std::true_type{});
+    if (g < g_hi && !failed) {
+        if (out_bit == 31)
+            steady_groups(g, std::false_type{});
+        else
+            steady_groups(g, std::true_type{});
+    }
     for (; g < ngroups && !failed; ++g) checked_group(g);
     if (failed) return;
 #ifdef BMX_EXPERIMENTS

@@ -177,6 +177,7 @@ struct bmx_ctx {
     int ed_lag = 0;              // >= 0 with ed_lag_set: rows a band is assumed to trail its predecessor by
     bool ed_lag_set = false;
     int ed_group = 32;           // hand-over group of the band pipeline (16 or 32 rows)
+    int ed_stamp_block = -1;     // libbmx_exp.so: the band whose cycle counts bmx_exp_ed_stamps returns (< 0: the middle forward band)
     int ed_step_x = 0;           // libbmx_exp.so: timing experiment on the helper-wave band's step (index into g_ed_step_experiments)
     int sa_flags = 0;            // suffix array: 1 = library rounds only, 2 = a host wait per round, 4 = per-round trace on stderr
     const void *last_text = nullptr; // the text of the search whose status is awaited (its order_kernel samples it again)
@@ -1127,7 +1128,7 @@ const EdVariant g_ed_variants[] = {
      bmx::ed_bits2_lds(32, 1), 190, 25.0},
     // 13: ... with a helper wave per band that talks to the neighbouring bands (bmx_ed_bits3_kernel.h): groups of 32 / 16 steps
     {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits3_kernel<32, 2>, bmx::ed_bits3_kernel<16, 2>,
-     bmx::ed_bits3_lds(32, 2), 480, 16.0, 128},
+     bmx::ed_bits3_lds(32, 2), 500, 14.0, 256},
 };
 #ifdef BMX_EXPERIMENTS
 void (*const g_ed_step_experiments[])(const bmx::EdBandArgs) = {
@@ -1210,6 +1211,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     a.lag = lag;
 #ifdef BMX_EXPERIMENTS
     a.stamps = (uint64_t *)((char *)ws + stamp_at);
+    a.stamp_block = ctx->ed_stamp_block >= 0 ? (uint32_t)ctx->ed_stamp_block : bands / 2;
 #endif
     // generous: 10 s + 100x the time the tile schedule would need (100 MHz ticks)
     a.timeout_ticks = 1000000000ull + (uint64_t)((double)la * (double)lb / 2.0e9 * 100.0);
@@ -1223,7 +1225,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     if (e == hipSuccess) {
         auto kern = ctx->ed_group == 16 ? v.band16 : v.band;
 #ifdef BMX_EXPERIMENTS
-        if (ctx->ed_step_x > 0 && v.band_threads == 128 && ctx->ed_step_x < (int)(sizeof g_ed_step_experiments / sizeof g_ed_step_experiments[0]))
+        if (ctx->ed_step_x > 0 && v.band_threads == 256 && ctx->ed_step_x < (int)(sizeof g_ed_step_experiments / sizeof g_ed_step_experiments[0]))
             kern = g_ed_step_experiments[ctx->ed_step_x];
 #endif
         if (v.band_lds > 64 * 1024) e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.band_lds);
@@ -1597,6 +1599,7 @@ int bmx_exp_set_knob(bmx_ctx *ctx, const char *name, int value)
     else if (k == "ed_lag") ctx->ed_lag = value, ctx->ed_lag_set = value >= 0;
     else if (k == "ed_group") ctx->ed_group = value;
     else if (k == "ed_step_x") ctx->ed_step_x = value;
+    else if (k == "ed_stamp_block") ctx->ed_stamp_block = value;
     else if (k == "sa_flags") ctx->sa_flags = value;
     else return BMX_ERR_ARG;
     return BMX_OK;

@@ -29,4 +29,13 @@ for v, grp in sel:
             st["cycles_per_step"] = round(st["cycles_in_steps"] / (st["groups"] * st["steps_per_group"]), 1)
             st["cycles_between_per_group"] = round(st["cycles_between"] / st["groups"], 1)
         out["stamps_middle_band_default_lag"] = st
+        if v == 13:  # the band nobody waits for but everybody waits on: forward band 0
+            ctx.set_knob("ed_stamp_block", 0)
+            ctx.edit_distance_device(x, z)
+            st = ctx.ed_stamps()
+            if st["groups"]:
+                st["cycles_per_step"] = round(st["cycles_in_steps"] / (st["groups"] * st["steps_per_group"]), 1)
+                st["cycles_between_per_group"] = round(st["cycles_between"] / st["groups"], 1)
+            out["stamps_band_0_default_lag"] = st
+            ctx.set_knob("ed_stamp_block", -1)
     print(json.dumps(out), flush=True)

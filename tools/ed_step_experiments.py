@@ -11,9 +11,9 @@ x = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 z = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 ctx = host.Context(0, library=host.exp_lib())
 ctx.set_ed_variant(13)
-ctx.set_knob("ed_lag", 400)
-names = ["the product step", "no writes to the outgoing ring", "no Eq requests", "row_shr instead of wave_shr", "no feed / character ring requests",
-         "no hand to the right", "no ring writes, no Eq requests", "no LDS instruction at all", "no LDS instruction, no DPP"]
+ctx.set_knob("ed_lag", 500)
+names = ["the product step", "band edge not collected", "no Eq-word requests", "row_shr instead of wave_shr", "no feed-ring requests",
+         "no hand to the right", "no edge collection, no Eq-word requests", "no LDS instruction at all", "no LDS instruction, no DPP"]
 for xi, name in enumerate(names):
     ctx.set_knob("ed_step_x", xi)
     ms = []
