@@ -14,7 +14,7 @@ extern "C" {
 /* A measurement / test switch of one context.  Names: "max_grid" (at most n workgroups per scan: texts of a few MiB
  * then reach the stolen tail), "no_dense" (no fill pass), "no_text_sample" (the walker goes by the pattern's symbols),
  * "multi_no_qgram" (multi-pattern pass byte-wise only), "ed_lag" (rows a column band is assumed to trail its
- * predecessor by; < 0: the measured default), "ed_group" (16 | 32 rows per hand-over), "sa_flags" (1 library rounds
+ * predecessor by; < 0: the measured default), "ed_group" (16 | 32 rows per hand-over), "ed_step_x" (1..8: ed variant 13 with parts of its step left out, timing only), "sa_flags" (1 library rounds
  * only, 2 a host wait per round, 4 per-round trace on stderr).  BMX_ERR_ARG for an unknown name. */
 int bmx_exp_set_knob(bmx_ctx *ctx, const char *name, int value);
 
@@ -25,7 +25,7 @@ int bmx_probe_read(bmx_ctx *ctx, const void *d_text, uint64_t n, int block, int 
                    int launches, float *ms_out, void *stream);
 
 /* Cycle counts (s_memtime) of the band in the middle of the forward pipeline of the last bmx_edit_distance_device call that
- * ran the reworked bit-parallel band (ed variants 11, 12): out8 = {groups of unrolled steps, cycles inside them, cycles between
+ * ran a reworked bit-parallel band (ed variants 11, 12, 13; knob "ed_stamp_block": which band, default the middle forward one): out8 = {groups of unrolled steps, cycles inside them, cycles between
  * them (validate, ring, hand-over, request), cycles of the whole loop, of which in validate (waiting included), steps per
  * group, rows per step, steps of the band}. */
 int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out8);
