@@ -27,8 +27,11 @@ int bmx_probe_read(bmx_ctx *ctx, const void *d_text, uint64_t n, int block, int 
 /* Cycle counts (s_memtime) of the band in the middle of the forward pipeline of the last bmx_edit_distance_device call that
  * ran a reworked bit-parallel band (ed variants 11, 12, 13; knob "ed_stamp_block": which band, default the middle forward one): out8 = {groups of unrolled steps, cycles inside them, cycles between
  * them (validate, ring, hand-over, request), cycles of the whole loop, of which in validate (waiting included), steps per
- * group, rows per step, steps of the band}. */
-int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out8);
+ * group, rows per step, steps of the band}; out16[8..15] (ed variant 13): one hand-over's timeline in 10-ns ticks of the 100 MHz
+ * clock all CUs share -- the stamped band's main wave at the end of its group 200, its publisher behind that group's stores; in
+ * the band behind: the feeder when the batch those entries complete is valid / fed, the Eq-word wave when its words are there, the
+ * main wave at the start of the group that needed them (0: not reached). */
+int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out16);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,7 @@
 namespace bmx {
 
 constexpr uint32_t ED_BITS3_CHARS = 512; // entries of the character ring
+constexpr uint32_t ED_BITS3_TL_GROUP = 200; // libbmx_exp.so: the group whose hand-over bmx_exp_ed_stamps times
 constexpr uint32_t ed_bits3_lds(uint32_t group, uint32_t rows)
 {
     // Eq table | feed ring | character ring | counters | outgoing ring | Eq-word ring
@@ -232,6 +233,10 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
             bool progress = false;
             if (handed < ngroups && stepped > handed) { // the band behind waits for this: first
                 publish(handed);
+#ifdef BMX_EXPERIMENTS
+                if (a.stamps != nullptr && blockIdx.x == a.stamp_block && handed == ED_BITS3_TL_GROUP && lane == 0)
+                    a.stamps[9] = __builtin_amdgcn_s_memrealtime();
+#endif
                 ++handed;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the ring has been read: the main wave may write it again)
                 flag_write(2, handed);
@@ -246,9 +251,16 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
 #pragma unroll
                 for (uint32_t q = 0; q < R; ++q) bad = bad || (uint32_t)(nxt.left[q] >> 32) != a.tag;
                 if (__ballot(bad) == 0) {
+#ifdef BMX_EXPERIMENTS
+                    const bool tl = a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && fed == ED_BITS3_TL_GROUP - 1 && lane == 0;
+                    if (tl) a.stamps[12] = __builtin_amdgcn_s_memrealtime();
+#endif
                     to_rings(nxt, fed);
                     ++fed;
                     flag_write(4, fed);
+#ifdef BMX_EXPERIMENTS
+                    if (tl) a.stamps[13] = __builtin_amdgcn_s_memrealtime();
+#endif
                     progress = true;
                     if (fed < nbatches) nxt = load_batch(fed);
                     else requested = false;
@@ -274,6 +286,9 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
         // address arithmetic) where it spent five (character request, two SDWA adds, two Eq requests: 25 + 11 cycles of its 203).
         // Runs as far ahead as the characters are fed and the ring has room.
         uint32_t t = 0, polls = 0;
+#ifdef BMX_EXPERIMENTS
+        bool tl_done = false;
+#endif
         while (t <= steps) { // (the main wave's last step still requests the slot of the step behind it)
             const ed_u32x4 fl = flags_read4();
             if (__builtin_amdgcn_readfirstlane(fl.w) != 0) return;
@@ -321,6 +336,12 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             flag_write(0, t);
+#ifdef BMX_EXPERIMENTS
+            if (a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && lane == 0 && !tl_done && t >= (ED_BITS3_TL_GROUP - 1) * G + 1) {
+                a.stamps[14] = __builtin_amdgcn_s_memrealtime();
+                tl_done = true;
+            }
+#endif
         }
         return;
     }
@@ -505,6 +526,8 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
             }
             aim(g);
 #ifdef BMX_EXPERIMENTS
+            if (a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && g == ED_BITS3_TL_GROUP - 2 && lane == 0)
+                a.stamps[15] = __builtin_amdgcn_s_memrealtime();
             uint64_t st_t0 = 0;
             if (stamped) {
                 st_t0 = __builtin_amdgcn_s_memtime();
@@ -521,6 +544,10 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
 #endif
             ++g;
             flag_write(1, g);
+#ifdef BMX_EXPERIMENTS
+            if (a.stamps != nullptr && blockIdx.x == a.stamp_block && g == ED_BITS3_TL_GROUP + 1 && lane == 0)
+                a.stamps[8] = __builtin_amdgcn_s_memrealtime();
+#endif
         } while (g < g_hi);
     };
     uint32_t g = 0;

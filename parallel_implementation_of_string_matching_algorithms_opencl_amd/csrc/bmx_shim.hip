@@ -184,7 +184,7 @@ struct bmx_ctx {
     uint64_t last_text_n = 0;
     int last_variant = 0;    // what the most recent search ran (bmx_scan_geometry reports it)
     int ed_variant = 0;      // edit-distance tile shape (bmx_set_ed_variant)
-    uint64_t ed_stamps[8] = {}; // libbmx_exp.so: cycle counts of one band of the last band-pipeline run
+    uint64_t ed_stamps[16] = {}; // libbmx_exp.so: cycle counts of one band of the last band-pipeline run + a hand-over's timeline
     float ed_last_ms = -1.0f;
     void *ed_ws = nullptr;   // band pipeline workspace, kept between calls while it is small
     uint64_t ed_ws_bytes = 0;
@@ -1155,7 +1155,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     // [right columns: 2 x (bands + 1) x (lb + 1) entries of 8 B | cut rows: 2 x bands x (W + 1) | cut | err | result]
     const uint64_t rc_entries = 2ull * (bands + 1) * (lb + 1), stair_words = 2ull * bands * (W + 1);
     const uint64_t stamp_at = (rc_entries * sizeof(uint64_t) + (stair_words + bands + 2) * sizeof(uint32_t) + 7) / 8 * 8;
-    const uint64_t bytes = stamp_at + 8 * sizeof(uint64_t);
+    const uint64_t bytes = stamp_at + 16 * sizeof(uint64_t);
     if (bytes > ED_BAND_WS_LIMIT || la + lb >= (1ull << 31)) return BMX_OK; // (the kernel's F = D - r - c is an int32)
     // Workspace: kept in the context between calls while it is small (a fresh hipMalloc + hipFree per
     // call costs 0.3 ms next to a 4 ms kernel).  Entries are valid only with this call's tag; tags are
@@ -1581,10 +1581,10 @@ int bmx_search_ranges(bmx_ctx *ctx_in, const char *text, uint64_t n, const char 
 #ifdef BMX_EXPERIMENTS
 // libbmx_exp.so only: the measurement / test switches of a context (round 2 read them from the environment on every call,
 // in the product library too).  Returns BMX_ERR_ARG for an unknown name.
-int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out8)
+int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out16)
 {
-    if (!ctx || !out8) return BMX_ERR_ARG;
-    for (int i = 0; i < 8; ++i) out8[i] = ctx->ed_stamps[i];
+    if (!ctx || !out16) return BMX_ERR_ARG;
+    for (int i = 0; i < 16; ++i) out16[i] = ctx->ed_stamps[i];
     return BMX_OK;
 }
 

@@ -224,10 +224,15 @@ class Context:
 
     def ed_stamps(self):
         """libbmx_exp.so only (bmx_exp_ed_stamps): cycle counts of one band of the last edit distance (ed variants 11, 12)."""
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         self._chk(self._L.bmx_exp_ed_stamps(self._h, out), "bmx_exp_ed_stamps")
         keys = ["groups", "cycles_in_steps", "cycles_between", "cycles_loop", "cycles_validate", "steps_per_group", "rows_per_step", "band_steps"]
-        return dict(zip(keys, [int(v) for v in out]))
+        d = dict(zip(keys, [int(v) for v in out[:8]]))
+        t = [int(v) for v in out[8:16]]
+        if t[0]:  # one hand-over's timeline, microseconds after the band in front finished its group 200
+            names = ["publisher_stores_issued", None, None, "feeder_batch_valid", "feeder_batch_fed", "eq_words_there", "main_behind_starts_group"]
+            d["handover_us"] = {n: round((t[i + 1] - t[0]) / 100.0, 2) for i, n in enumerate(names) if n and t[i + 1]}
+        return d
 
     def __del__(self):
         try:

@@ -37,5 +37,8 @@ for v, grp in sel:
                 st["cycles_per_step"] = round(st["cycles_in_steps"] / (st["groups"] * st["steps_per_group"]), 1)
                 st["cycles_between_per_group"] = round(st["cycles_between"] / st["groups"], 1)
             out["stamps_band_0_default_lag"] = st
+            ctx.set_knob("ed_stamp_block", 5)  # (the timeline of a hand-over between forward bands 5 and 6)
+            ctx.edit_distance_device(x, z)
+            out["handover_band_5_to_6_us"] = ctx.ed_stamps().get("handover_us")
             ctx.set_knob("ed_stamp_block", -1)
     print(json.dumps(out), flush=True)
