@@ -94,9 +94,25 @@ def self_launch(n_ranks: int) -> int:
     import socket
     import subprocess
 
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    # a rendezvous port nobody listens on, outside the kernel's ephemeral range (a port from bind(0) can be taken by any outgoing
+    # connection between this probe and the ranks' bind)
+    import random
+
+    port = None
+    rng = random.Random(os.getpid() ^ int.from_bytes(os.urandom(4), "little"))
+    for _ in range(200):
+        cand = rng.randrange(20000, 30000)
+        with socket.socket() as sock:
+            try:
+                sock.bind(("127.0.0.1", cand))
+            except OSError:
+                continue
+            port = cand
+            break
+    if port is None:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
     procs = []
     for r in range(n_ranks):
         env = dict(os.environ)

@@ -96,13 +96,15 @@ __global__ __launch_bounds__(64) void ed_bits2_kernel(const EdBandArgs a)
     // the Eq table: zeroed by the wave, then every lane sets the bits of its 32 columns in its own column of the table
     for (uint32_t i = lane; i < ED_BITS2_PEQ_WORDS + ED_BITS2_FEED_WORDS; i += 64) ed_lds[i] = 0u;
     __syncthreads();
+    uint8_t col_chars[32]; // (all 32 requests first: one memory round trip, not 32)
+#pragma unroll
     for (uint32_t k = 0; k < 32; ++k) {
         const uint32_t cc = lane * 32 + k;
-        if (cc < ncols) {
-            const uint32_t ch = a.a[mirror ? col0 + ncols - 1 - cc : col0 + cc];
-            peq[ch * 64 + lane] |= 1u << k; // (padding columns match nothing)
-        }
+        col_chars[k] = a.a[cc < ncols ? (mirror ? col0 + ncols - 1 - cc : col0 + cc) : col0];
     }
+#pragma unroll
+    for (uint32_t k = 0; k < 32; ++k)
+        if (lane * 32 + k < ncols) peq[(uint32_t)col_chars[k] * 64 + lane] |= 1u << k; // (padding columns match nothing)
     __syncthreads();
     if (lane == 0) my_rc[phys_r(0)] = ed_entry(0u, a.tag); // my far edge on the table's edge row
 

@@ -29,7 +29,7 @@
 // fed).  LDS instructions of a wave complete in order, so "data, then counter" needs no wait on the writer's side.  Batches end
 // where the groups of the band in front end (entries up to k G with its group k + 1): a batch is complete with ONE group.
 // What goes to HBM is what went there before ({F, tag} per row): the value bands, the meet kernel and the cut rows do not change.
-// Measured (64k x 64k, profiles/r03_ed_*): 2.20 ms (bits2) -> 1.64 ms; per step 174 cycles, 390 between groups, lag 250 steps.
+// Measured (64k x 64k, profiles/r03_ed_*): 2.20 ms (bits2) -> 1.49 ms; per step 172 cycles, ~300 between groups, lag 180 steps.
 //
 // Reference: EditDistance-1/EditDistance-1/kernal.cl:5-56 + EditDistance-1.cpp:278-345; recurrence as sequential.c:18-46.
 #pragma once
@@ -100,13 +100,15 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
     for (uint32_t i = threadIdx.x; i < (uint32_t)(outw - ed_lds); i += 256) ed_lds[i] = 0u;
     __syncthreads();
     if (wave == 0) {
+        uint8_t col_chars[32]; // (all 32 requests first: one memory round trip, not 32)
+#pragma unroll
         for (uint32_t k = 0; k < 32; ++k) {
             const uint32_t cc = lane * 32 + k;
-            if (cc < ncols) {
-                const uint32_t ch = a.a[mirror ? col0 + ncols - 1 - cc : col0 + cc];
-                peq[ch * 64 + lane] |= 1u << k; // (padding columns match nothing)
-            }
+            col_chars[k] = a.a[cc < ncols ? (mirror ? col0 + ncols - 1 - cc : col0 + cc) : col0];
         }
+#pragma unroll
+        for (uint32_t k = 0; k < 32; ++k)
+            if (lane * 32 + k < ncols) peq[(uint32_t)col_chars[k] * 64 + lane] |= 1u << k; // (padding columns match nothing)
         if (lane == 0) my_rc[phys_r(0)] = ed_entry(0u, a.tag); // my far edge on the table's edge row
     }
     __syncthreads();
@@ -318,17 +320,25 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
                 *dst = make_uint2(e0, e1);
                 if (slot == 0) dst[EQR * 64] = make_uint2(e0, e1); // a group's last step reads one slot on
             };
-            for (; t + 4 <= hi; t += 4) { // four steps' requests in flight together
-                uint32_t ch[4], eq[4][2];
+            // (a lane that has not started -- step < lane, only in the first 63 steps -- gets no match anywhere: see the main wave's
+            // groups.  The selects are written as masks: as conditions hipcc put every request under its own exec mask and branch,
+            // and this wave could no longer keep up with the main wave.)
+            for (; t < hi && t < 64; ++t) {
+                const uint32_t chars = crng[(t - lane) & (ED_BITS3_CHARS - 1)];
+                const uint32_t keep = 0u - (uint32_t)(t >= lane);
+                put(t, eq_word(chars, 0) & keep, R > 1 ? eq_word(chars, 1) & keep : 0u);
+            }
+            for (; t + 8 <= hi; t += 8) { // eight steps' requests in flight together
+                uint32_t ch[8], eq[8][2];
 #pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) ch[i] = crng[(t + i - lane) & (ED_BITS3_CHARS - 1)];
+                for (uint32_t i = 0; i < 8; ++i) ch[i] = crng[(t + i - lane) & (ED_BITS3_CHARS - 1)];
 #pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) {
+                for (uint32_t i = 0; i < 8; ++i) {
                     eq[i][0] = eq_word(ch[i], 0);
                     eq[i][1] = R > 1 ? eq_word(ch[i], 1) : 0u;
                 }
 #pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) put(t + i, eq[i][0], eq[i][1]);
+                for (uint32_t i = 0; i < 8; ++i) put(t + i, eq[i][0], eq[i][1]);
             }
             for (; t < hi; ++t) {
                 const uint32_t chars = crng[(t - lane) & (ED_BITS3_CHARS - 1)];
@@ -489,14 +499,6 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
         const uint32_t s0 = g * G;
         admit(g);
         if (failed) return;
-        if (g == 0) { // entry 0 and step 0's Eq words are there
-            ed_u32x2 e0;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(ent) : "v"(feed_base) : "memory");
-            asm volatile("ds_read_b64 %0, %1" : "=v"(e0) : "v"(eqr_base) : "memory");
-            settle(e0, ent, std::integral_constant<uint32_t, 0>{});
-#pragma unroll
-            for (uint32_t q = 0; q < R; ++q) eq_cur[q] = e0[q];
-        }
         aim(g);
         const uint32_t n = steps - s0 < G ? steps - s0 : G;
         for (uint32_t j = 0; j < n; ++j) {
@@ -512,8 +514,11 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
         }
         flag_write(1, g + 1); // behind the group's writes to the outgoing ring
     };
-    // every lane has a whole entry in each step of the groups [g_lo, g_hi): their steps need no checks and are unrolled
-    const uint32_t g_lo = (63 + G - 1) / G;
+    // Every lane that has started has a whole entry in each step of the groups [0, g_hi): their steps need no checks and are
+    // unrolled.  A lane that has NOT started (step < lane) runs them too and stays as it is: its Eq words are 0 (the Eq-word wave
+    // sees to that) and what enters from the left is 0 (its left neighbour has not started either: Ph = Mh = 0), and the recurrence
+    // maps (Pv, Mv) = (~0, 0) to itself then.  (The first two groups ran the checked step at ~300 cycles against 176: a band fell
+    // ~45 steps behind the one in front in its first 64 steps and never caught up.)
     const uint32_t g_hi_raw = nrows / (G * R);
     const uint32_t g_hi = g_hi_raw < ngroups ? g_hi_raw : ngroups;
     // (one forward branch not taken, one backward branch taken per group: a taken branch costs this lone wave a refill of its
@@ -551,7 +556,15 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
         } while (g < g_hi);
     };
     uint32_t g = 0;
-    for (; g < ngroups && (g < g_lo || g >= g_hi) && !failed; ++g) checked_group(g);
+    admit(0);
+    if (!failed) { // entry 0 and step 0's Eq words are there
+        ed_u32x2 e0;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ent) : "v"(feed_base) : "memory");
+        asm volatile("ds_read_b64 %0, %1" : "=v"(e0) : "v"(eqr_base) : "memory");
+        settle(e0, ent, std::integral_constant<uint32_t, 0>{});
+#pragma unroll
+        for (uint32_t q = 0; q < R; ++q) eq_cur[q] = e0[q];
+    }
 #ifdef BMX_EXPERIMENTS
     if (stamped) st_mark = __builtin_amdgcn_s_memtime();
 #endif

@@ -1128,7 +1128,7 @@ const EdVariant g_ed_variants[] = {
      bmx::ed_bits2_lds(32, 1), 190, 25.0},
     // 13: ... with a helper wave per band that talks to the neighbouring bands (bmx_ed_bits3_kernel.h): groups of 32 / 16 steps
     {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits3_kernel<32, 2>, bmx::ed_bits3_kernel<16, 2>,
-     bmx::ed_bits3_lds(32, 2), 500, 14.0, 256},
+     bmx::ed_bits3_lds(32, 2), 360, 14.0, 256},
 };
 #ifdef BMX_EXPERIMENTS
 void (*const g_ed_step_experiments[])(const bmx::EdBandArgs) = {

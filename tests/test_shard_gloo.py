@@ -15,6 +15,19 @@ from parallel_implementation_of_string_matching_algorithms_opencl_amd import cor
 
 
 def _free_port():
+    """A port nobody listens on, OUTSIDE the kernel's ephemeral range (32768-60999): a port handed out by bind(0) can be taken
+    by any outgoing connection of the box between this probe and the rendezvous that binds it again (seen once: EADDRINUSE)."""
+    import random
+
+    rng = random.Random(os.getpid() ^ int.from_bytes(os.urandom(4), "little"))
+    for _ in range(200):
+        cand = rng.randrange(20000, 30000)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", cand))
+            except OSError:
+                continue
+            return cand
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
