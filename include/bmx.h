@@ -280,9 +280,13 @@ int bmx_edit_distance_device(bmx_ctx *ctx, const void *d_a, uint64_t la, const v
                              uint64_t *distance, void *stream);
 /* Device time (ms, HIP events around the kernels) of the last call. */
 float bmx_last_edit_distance_ms(bmx_ctx *ctx);
-/* Kernel shape for experiments: 0 = default (one launch, a pipeline of column bands of 384
- * columns from both corners of the table); +32 = one launch per pair of tile diagonals from
- * both corners; +16 = one launch per tile diagonal from the top-left corner only. */
+/* Schedule, for experiments: 0 = the library's choice (one launch: a pipeline of bit-parallel
+ * column bands of 2,048 columns from both corners of the table, a band = a workgroup of four waves,
+ * csrc/bmx_ed_bits3_kernel.h = schedule 13); 1..7 = value bands of 64 C columns and their tile
+ * shapes; 8..10 = the first bit-parallel band, 1 / 2 / 4 rows per step; 11, 12 = one wave per
+ * band with everything but the recurrence out of the step; +32 = one launch per pair of tile
+ * diagonals from both corners; +16 = one launch per tile diagonal from the top-left corner only.
+ * Every schedule returns the same distance. */
 int bmx_set_ed_variant(bmx_ctx *ctx, int variant);
 
 /* ---- suffix array: the reference's third program -------------------- */
