@@ -30,8 +30,10 @@ int bmx_probe_read(bmx_ctx *ctx, const void *d_text, uint64_t n, int block, int 
  * group, rows per step, steps of the band}; out16[8..15] (ed variant 13): one hand-over's timeline in 10-ns ticks of the 100 MHz
  * clock all CUs share -- the stamped band's main wave at the end of its group 200, its publisher behind that group's stores; in
  * the band behind: the feeder when the batch those entries complete is valid / fed, the Eq-word wave when its words are there, the
- * main wave at the start of the group that needed them (0: not reached). */
-int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out16);
+ * main wave at the start of the group that needed them (0: not reached); [10], [11], [16..18]: the same chain at the START of the run (the band
+ * in front ends its group 2 / the band behind starts its first group; batch 1 fed, Eq words of 33 steps there, group 2 published); [24 + 4 b + k], b < 64: the clock when band (block) b finished its
+ * groups 1, 100, 300 and 500 (0: it has fewer). */
+int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out280);
 
 #ifdef __cplusplus
 }

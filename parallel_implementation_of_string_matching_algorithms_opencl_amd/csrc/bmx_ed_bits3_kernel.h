@@ -238,6 +238,8 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
 #ifdef BMX_EXPERIMENTS
                 if (a.stamps != nullptr && blockIdx.x == a.stamp_block && handed == ED_BITS3_TL_GROUP && lane == 0)
                     a.stamps[9] = __builtin_amdgcn_s_memrealtime();
+                if (a.stamps != nullptr && blockIdx.x == a.stamp_block && handed == 2 && lane == 0)
+                    a.stamps[18] = __builtin_amdgcn_s_memrealtime();
 #endif
                 ++handed;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the ring has been read: the main wave may write it again)
@@ -262,6 +264,8 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
                     flag_write(4, fed);
 #ifdef BMX_EXPERIMENTS
                     if (tl) a.stamps[13] = __builtin_amdgcn_s_memrealtime();
+                    if (a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && fed == 2 && lane == 0)
+                        a.stamps[16] = __builtin_amdgcn_s_memrealtime();
 #endif
                     progress = true;
                     if (fed < nbatches) nxt = load_batch(fed);
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
         // Runs as far ahead as the characters are fed and the ring has room.
         uint32_t t = 0, polls = 0;
 #ifdef BMX_EXPERIMENTS
-        bool tl_done = false;
+        bool tl_done = false, tl_first = false;
 #endif
         while (t <= steps) { // (the main wave's last step still requests the slot of the step behind it)
             const ed_u32x4 fl = flags_read4();
@@ -322,27 +326,39 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
             };
             // (a lane that has not started -- step < lane, only in the first 63 steps -- gets no match anywhere: see the main wave's
             // groups.  The selects are written as masks: as conditions hipcc put every request under its own exec mask and branch,
-            // and this wave could no longer keep up with the main wave.)
-            for (; t < hi && t < 64; ++t) {
-                const uint32_t chars = crng[(t - lane) & (ED_BITS3_CHARS - 1)];
-                const uint32_t keep = 0u - (uint32_t)(t >= lane);
-                put(t, eq_word(chars, 0) & keep, R > 1 ? eq_word(chars, 1) & keep : 0u);
-            }
-            for (; t + 8 <= hi; t += 8) { // eight steps' requests in flight together
-                uint32_t ch[8], eq[8][2];
+            // and this wave could no longer keep up with the main wave.  And the first 64 steps go sixteen at a time like all others:
+            // one at a time they took 3.2 us for a band's first 33 steps, which every band behind then trailed by for good.)
+            while (t < hi) {
+                const uint32_t s0 = t & (EQR - 1);
+                if (t + 16 <= hi && s0 + 16 <= EQR) { // sixteen steps' requests in flight together, every address an immediate
+                    const uint32_t *cp = crng + ((t - lane) & (ED_BITS3_CHARS - 1)); // (the ring's first G entries again behind it)
+                    uint2 *dst = reinterpret_cast<uint2 *>(eqr) + s0 * 64 + lane;
+                    uint32_t ch[16], eq[16][2];
 #pragma unroll
-                for (uint32_t i = 0; i < 8; ++i) ch[i] = crng[(t + i - lane) & (ED_BITS3_CHARS - 1)];
+                    for (uint32_t i = 0; i < 16; ++i) ch[i] = cp[i];
 #pragma unroll
-                for (uint32_t i = 0; i < 8; ++i) {
-                    eq[i][0] = eq_word(ch[i], 0);
-                    eq[i][1] = R > 1 ? eq_word(ch[i], 1) : 0u;
+                    for (uint32_t i = 0; i < 16; ++i) {
+                        eq[i][0] = eq_word(ch[i], 0);
+                        eq[i][1] = R > 1 ? eq_word(ch[i], 1) : 0u;
+                    }
+                    if (t < 64) { // some lanes have not started
+#pragma unroll
+                        for (uint32_t i = 0; i < 16; ++i) {
+                            const uint32_t keep = 0u - (uint32_t)(t + i >= lane);
+                            eq[i][0] &= keep;
+                            eq[i][1] &= keep;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t i = 0; i < 16; ++i) dst[i * 64] = make_uint2(eq[i][0], eq[i][1]);
+                    if (s0 == 0) dst[EQR * 64] = make_uint2(eq[0][0], eq[0][1]); // a group's last step reads one slot on
+                    t += 16;
+                } else {
+                    const uint32_t chars = crng[(t - lane) & (ED_BITS3_CHARS - 1)];
+                    const uint32_t keep = 0u - (uint32_t)(t >= lane);
+                    put(t, eq_word(chars, 0) & keep, R > 1 ? eq_word(chars, 1) & keep : 0u);
+                    ++t;
                 }
-#pragma unroll
-                for (uint32_t i = 0; i < 8; ++i) put(t + i, eq[i][0], eq[i][1]);
-            }
-            for (; t < hi; ++t) {
-                const uint32_t chars = crng[(t - lane) & (ED_BITS3_CHARS - 1)];
-                put(t, eq_word(chars, 0), R > 1 ? eq_word(chars, 1) : 0u);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             flag_write(0, t);
@@ -350,6 +366,10 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
             if (a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && lane == 0 && !tl_done && t >= (ED_BITS3_TL_GROUP - 1) * G + 1) {
                 a.stamps[14] = __builtin_amdgcn_s_memrealtime();
                 tl_done = true;
+            }
+            if (a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && lane == 0 && !tl_first && t >= G + 1) {
+                a.stamps[17] = __builtin_amdgcn_s_memrealtime();
+                tl_first = true;
             }
 #endif
         }
@@ -383,6 +403,11 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
             asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w), "+v"(e)::"memory");
     };
 
+    // The other waves' counters, requested in the last step of an unrolled group (they arrive behind that step's wait): the next
+    // group is admitted by values one step old at the price of one LDS instruction.  (Read when the last read values no longer
+    // sufficed, they cost an LDS round trip per group on every band but band 0, whose helpers run groups ahead: band 1 fell 11 us
+    // behind band 0 over a run, the next bands a few more -- tools/ed_band_clock.py.)
+    ed_u32x4 flags_far = {0, 0, 0, 0};
     // One step: R rows of my 32 columns.  JC = the step's number within its group where the group is unrolled (ring addresses are
     // then immediates); else 0 and the addresses move.
     auto step = [&](uint32_t s, auto check_tag, auto jc, auto narrow_tag) {
@@ -403,6 +428,7 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
         } else {
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(eq_far) : "v"(eq_addr), "n"((JC + 1) * 512) : "memory"); // step s + 1's
         }
+        if constexpr (!CHECK && JC == G - 1) asm volatile("ds_read_b128 %0, %1" : "=v"(flags_far) : "v"(flags_addr) : "memory");
         // (the rows below start from Pv / Mv: passed through here, they cannot be scheduled in front of the requests)
         asm volatile("" : "+v"(Pv), "+v"(Mv));
 #pragma unroll
@@ -447,6 +473,7 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
                          : "v"(out_addr), "v"(acc_p), "v"(acc_m), "n"(((JC + 1) * R / 32 - 1) * 128), "n"(((JC + 1) * R / 32 - 1) * 128 + 1)
                          : "memory");
         settle(eq_far, ent_far, std::integral_constant<uint32_t, FLUSH ? 1 : 0>{});
+        if constexpr (!CHECK && JC == G - 1) asm volatile("" : "+v"(flags_far)); // (behind the same wait)
 #pragma unroll
         for (uint32_t q = 0; q < R; ++q) eq_cur[q] = eq_far[q];
         ent = ent_far;
@@ -533,6 +560,8 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
 #ifdef BMX_EXPERIMENTS
             if (a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && g == ED_BITS3_TL_GROUP - 2 && lane == 0)
                 a.stamps[15] = __builtin_amdgcn_s_memrealtime();
+            if (a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && g == 0 && lane == 0)
+                a.stamps[11] = __builtin_amdgcn_s_memrealtime();
             uint64_t st_t0 = 0;
             if (stamped) {
                 st_t0 = __builtin_amdgcn_s_memtime();
@@ -549,9 +578,19 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
 #endif
             ++g;
             flag_write(1, g);
+            have_eq = __builtin_amdgcn_readfirstlane(flags_far.x);
+            have_handed = __builtin_amdgcn_readfirstlane(flags_far.z);
+            if (__builtin_amdgcn_readfirstlane(flags_far.w) != 0) {
+                failed = true;
+                return;
+            }
 #ifdef BMX_EXPERIMENTS
             if (a.stamps != nullptr && blockIdx.x == a.stamp_block && g == ED_BITS3_TL_GROUP + 1 && lane == 0)
                 a.stamps[8] = __builtin_amdgcn_s_memrealtime();
+            if (a.stamps != nullptr && blockIdx.x < 64 && lane == 0 && (g == 1 || g == 100 || g == 300 || g == 500))
+                a.stamps[24 + 4 * blockIdx.x + (g == 1 ? 0 : g == 100 ? 1 : g == 300 ? 2 : 3)] = __builtin_amdgcn_s_memrealtime();
+            if (a.stamps != nullptr && blockIdx.x == a.stamp_block && g == 3 && lane == 0) // (its group 2 completes the band behind's batch 1)
+                a.stamps[10] = __builtin_amdgcn_s_memrealtime();
 #endif
         } while (g < g_hi);
     };

@@ -184,7 +184,7 @@ struct bmx_ctx {
     uint64_t last_text_n = 0;
     int last_variant = 0;    // what the most recent search ran (bmx_scan_geometry reports it)
     int ed_variant = 0;      // edit-distance tile shape (bmx_set_ed_variant)
-    uint64_t ed_stamps[16] = {}; // libbmx_exp.so: cycle counts of one band of the last band-pipeline run + a hand-over's timeline
+    uint64_t ed_stamps[24 + 64 * 4] = {}; // libbmx_exp.so: cycle counts of one band of the last band-pipeline run + a hand-over's timeline
     float ed_last_ms = -1.0f;
     void *ed_ws = nullptr;   // band pipeline workspace, kept between calls while it is small
     uint64_t ed_ws_bytes = 0;
@@ -1128,7 +1128,7 @@ const EdVariant g_ed_variants[] = {
      bmx::ed_bits2_lds(32, 1), 190, 25.0},
     // 13: ... with a helper wave per band that talks to the neighbouring bands (bmx_ed_bits3_kernel.h): groups of 32 / 16 steps
     {4, 256, bmx::ed_tile_kernel<4, 256, true>, bmx::ed_dual_kernel<4, 256>, 32, bmx::ed_bits3_kernel<32, 2>, bmx::ed_bits3_kernel<16, 2>,
-     bmx::ed_bits3_lds(32, 2), 360, 14.0, 256},
+     bmx::ed_bits3_lds(32, 2), 310, 14.0, 256},
 };
 #ifdef BMX_EXPERIMENTS
 void (*const g_ed_step_experiments[])(const bmx::EdBandArgs) = {
@@ -1155,7 +1155,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
     // [right columns: 2 x (bands + 1) x (lb + 1) entries of 8 B | cut rows: 2 x bands x (W + 1) | cut | err | result]
     const uint64_t rc_entries = 2ull * (bands + 1) * (lb + 1), stair_words = 2ull * bands * (W + 1);
     const uint64_t stamp_at = (rc_entries * sizeof(uint64_t) + (stair_words + bands + 2) * sizeof(uint32_t) + 7) / 8 * 8;
-    const uint64_t bytes = stamp_at + 16 * sizeof(uint64_t);
+    const uint64_t bytes = stamp_at + (24 + 64 * 4) * sizeof(uint64_t);
     if (bytes > ED_BAND_WS_LIMIT || la + lb >= (1ull << 31)) return BMX_OK; // (the kernel's F = D - r - c is an int32)
     // Workspace: kept in the context between calls while it is small (a fresh hipMalloc + hipFree per
     // call costs 0.3 ms next to a 4 ms kernel).  Entries are valid only with this call's tag; tags are
@@ -1212,6 +1212,7 @@ int ed_band_run(bmx_ctx *ctx, const EdVariant &v, const void *d_a, uint64_t la, 
 #ifdef BMX_EXPERIMENTS
     a.stamps = (uint64_t *)((char *)ws + stamp_at);
     a.stamp_block = ctx->ed_stamp_block >= 0 ? (uint32_t)ctx->ed_stamp_block : bands / 2;
+    (void)hipMemsetAsync(a.stamps, 0, (24 + 64 * 4) * sizeof(uint64_t), stream);
 #endif
     // generous: 10 s + 100x the time the tile schedule would need (100 MHz ticks)
     a.timeout_ticks = 1000000000ull + (uint64_t)((double)la * (double)lb / 2.0e9 * 100.0);
@@ -1581,10 +1582,10 @@ int bmx_search_ranges(bmx_ctx *ctx_in, const char *text, uint64_t n, const char 
 #ifdef BMX_EXPERIMENTS
 // libbmx_exp.so only: the measurement / test switches of a context (round 2 read them from the environment on every call,
 // in the product library too).  Returns BMX_ERR_ARG for an unknown name.
-int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out16)
+int bmx_exp_ed_stamps(bmx_ctx *ctx, uint64_t *out280)
 {
-    if (!ctx || !out16) return BMX_ERR_ARG;
-    for (int i = 0; i < 16; ++i) out16[i] = ctx->ed_stamps[i];
+    if (!ctx || !out280) return BMX_ERR_ARG;
+    for (int i = 0; i < 24 + 64 * 4; ++i) out280[i] = ctx->ed_stamps[i];
     return BMX_OK;
 }
 

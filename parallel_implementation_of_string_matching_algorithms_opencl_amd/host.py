@@ -224,7 +224,7 @@ class Context:
 
     def ed_stamps(self):
         """libbmx_exp.so only (bmx_exp_ed_stamps): cycle counts of one band of the last edit distance (ed variants 11, 12)."""
-        out = (C.c_uint64 * 16)()
+        out = (C.c_uint64 * (24 + 64 * 4))()
         self._chk(self._L.bmx_exp_ed_stamps(self._h, out), "bmx_exp_ed_stamps")
         keys = ["groups", "cycles_in_steps", "cycles_between", "cycles_loop", "cycles_validate", "steps_per_group", "rows_per_step", "band_steps"]
         d = dict(zip(keys, [int(v) for v in out[:8]]))
@@ -232,6 +232,11 @@ class Context:
         if t[0]:  # one hand-over's timeline, microseconds after the band in front finished its group 200
             names = ["publisher_stores_issued", None, None, "feeder_batch_valid", "feeder_batch_fed", "eq_words_there", "main_behind_starts_group"]
             d["handover_us"] = {n: round((t[i + 1] - t[0]) / 100.0, 2) for i, n in enumerate(names) if n and t[i + 1]}
+            if t[2] and t[3]:  # the start: the band behind begins its first group this long after the band in front ended its group 2
+                u = [int(v) for v in out[16:19]]
+                d["handover_us"]["at_the_start"] = {"group_2_in_front_published": round((u[2] - t[2]) / 100.0, 2), "batch_1_fed": round((u[0] - t[2]) / 100.0, 2),
+                                                     "eq_words_of_33_steps_there": round((u[1] - t[2]) / 100.0, 2), "first_group_behind_starts": round((t[3] - t[2]) / 100.0, 2)}
+        d["band_clock"] = [[int(out[24 + 4 * b + k]) for k in range(4)] for b in range(64)]
         return d
 
     def __del__(self):

@@ -11,7 +11,7 @@ x = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 z = torch.from_numpy((rng.integers(0, 4, n) + 65).astype(np.uint8)).cuda()
 ctx = host.Context(0, library=host.exp_lib())
 ctx.set_ed_variant(13)
-ctx.set_knob("ed_lag", 360)
+ctx.set_knob("ed_lag", 310)
 names = ["the product step", "band edge not collected", "no Eq-word requests", "row_shr instead of wave_shr", "no feed-ring requests",
          "no hand to the right", "no edge collection, no Eq-word requests", "no LDS instruction at all", "no LDS instruction, no DPP"]
 for xi, name in enumerate(names):
