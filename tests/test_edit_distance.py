@@ -149,6 +149,29 @@ def test_gpu_degenerate(ctx):
 
 
 @pytest.mark.gpu
+def test_gpu_every_byte_value_on_the_bit_parallel_bands(ctx, port):
+    """The bit-parallel bands index their Eq table by the character: all 256 byte values, NUL and 0xff included, on shapes with a
+    narrow last band, fewer rows than a group, rows that are not whole steps, and a band whose lanes have not all started when the
+    rows end (schedules 13 = the default, 11, 9)."""
+    rng = np.random.default_rng(29)
+    shapes = [(2048, 2048), (2049, 5), (4096 + 33, 127), (300, 4097), (6145, 2047), (70, 70), (2047, 129), (5000, 63)]
+    try:
+        for v in (13, 11, 9, 0):
+            ctx.set_ed_variant(v)
+            for la, lb in shapes:
+                x = rng.integers(0, 256, la).astype(np.uint8)
+                y = rng.integers(0, 256, lb).astype(np.uint8)
+                k = min(la, lb)
+                y[: k // 2] = x[: k // 2]  # (a long common prefix: the distance is not just max(la, lb))
+                x[la // 3] = 0
+                y[lb // 2] = 0
+                x[-1] = 255
+                assert ctx.edit_distance(x, y) == port.edit_distance(x, y), (v, la, lb)
+    finally:
+        ctx.set_ed_variant(0)
+
+
+@pytest.mark.gpu
 def test_gpu_mid_size_vs_oracle(ctx, port):
     rng = np.random.default_rng(3)
     x = (rng.integers(0, 4, 9000) + 65).astype(np.uint8)
