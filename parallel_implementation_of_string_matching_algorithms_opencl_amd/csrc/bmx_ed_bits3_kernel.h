@@ -222,65 +222,99 @@ __global__ __launch_bounds__(256) void ed_bits3_kernel(const EdBandArgs a)
             edge_f += __builtin_amdgcn_readlane(incl, 63);
         };
 
-        // two waves run this: the feeder (wave 1) only feeds, the publisher (wave 3) only hands over -- the feeder waits up to a
-        // memory round trip for a batch it has requested, and the band behind must not wait for that
-        const bool feeds = wave == 1;
-        uint32_t fed = feeds ? 0u : nbatches, handed = feeds ? ngroups : 0u, polls = 0;
-        Batch nxt = load_batch(0);
-        bool requested = true;
-        while (fed < nbatches || handed < ngroups) {
-            const ed_u32x4 fl = flags_read4();
-            const uint32_t stepped = __builtin_amdgcn_readfirstlane(fl.y);
-            if (__builtin_amdgcn_readfirstlane(fl.w) != 0) return;
-            bool progress = false;
-            if (handed < ngroups && stepped > handed) { // the band behind waits for this: first
-                publish(handed);
+        // Two waves run this code: the publisher (wave 3) only hands over, the feeder (wave 1) only feeds -- apart, because a
+        // request for a batch that is not there yet takes a memory round trip, and the band behind must not wait for that.
+        if (wave == 3) {
+            uint32_t handed = 0, polls = 0;
+            while (handed < ngroups) {
+                const ed_u32x4 fl = flags_read4();
+                if (__builtin_amdgcn_readfirstlane(fl.w) != 0) return;
+                if (__builtin_amdgcn_readfirstlane(fl.y) > handed) {
+                    publish(handed);
 #ifdef BMX_EXPERIMENTS
-                if (a.stamps != nullptr && blockIdx.x == a.stamp_block && handed == ED_BITS3_TL_GROUP && lane == 0)
-                    a.stamps[9] = __builtin_amdgcn_s_memrealtime();
-                if (a.stamps != nullptr && blockIdx.x == a.stamp_block && handed == 2 && lane == 0)
-                    a.stamps[18] = __builtin_amdgcn_s_memrealtime();
+                    if (a.stamps != nullptr && blockIdx.x == a.stamp_block && handed == ED_BITS3_TL_GROUP && lane == 0)
+                        a.stamps[9] = __builtin_amdgcn_s_memrealtime();
+                    if (a.stamps != nullptr && blockIdx.x == a.stamp_block && handed == 2 && lane == 0)
+                        a.stamps[18] = __builtin_amdgcn_s_memrealtime();
 #endif
-                ++handed;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the ring has been read: the main wave may write it again)
-                flag_write(2, handed);
-                progress = true;
-            }
-            if (fed < nbatches && fed <= stepped + 7) { // the rings have room for batch `fed`
-                if (!requested) {
-                    nxt = load_batch(fed);
-                    requested = true;
-                }
-                bool bad = false;
-#pragma unroll
-                for (uint32_t q = 0; q < R; ++q) bad = bad || (uint32_t)(nxt.left[q] >> 32) != a.tag;
-                if (__ballot(bad) == 0) {
-#ifdef BMX_EXPERIMENTS
-                    const bool tl = a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && fed == ED_BITS3_TL_GROUP - 1 && lane == 0;
-                    if (tl) a.stamps[12] = __builtin_amdgcn_s_memrealtime();
-#endif
-                    to_rings(nxt, fed);
-                    ++fed;
-                    flag_write(4, fed);
-#ifdef BMX_EXPERIMENTS
-                    if (tl) a.stamps[13] = __builtin_amdgcn_s_memrealtime();
-                    if (a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && fed == 2 && lane == 0)
-                        a.stamps[16] = __builtin_amdgcn_s_memrealtime();
-#endif
-                    progress = true;
-                    if (fed < nbatches) nxt = load_batch(fed);
-                    else requested = false;
+                    ++handed;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (the ring has been read: the main wave may write it again)
+                    flag_write(2, handed);
                 } else {
-                    requested = false; // ask again next time round
+                    if ((++polls & 63u) == 0 && hopeless()) {
+                        give_up();
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
             }
-            if (!progress) {
+            return;
+        }
+        // The feeder polls a batch with THREE requests in flight, a third of a round trip apart: a request that left just
+        // before the entries arrived comes back stale, and with one request at a time the next one would only leave then -- the
+        // batch was noticed 0.4 ... 1.7 us after it was there, and a band trails the one in front by the LONGEST hand-over it has
+        // ever seen (tools/ed_band_clock.py), not the mean.
+        auto valid = [&](const Batch &g) {
+            bool bad = false;
+#pragma unroll
+            for (uint32_t q = 0; q < R; ++q) bad = bad || (uint32_t)(g.left[q] >> 32) != a.tag;
+            return __ballot(bad) == 0;
+        };
+        constexpr uint32_t APART = 5; // s_sleep units of 64 cycles between two requests: ~0.13 us + the loop around them
+        uint32_t polls = 0;
+        for (uint32_t fed = 0; fed < nbatches;) {
+            for (;;) { // room in the rings for batch `fed`: the main wave within seven groups
+                const ed_u32x4 fl = flags_read4();
+                if (__builtin_amdgcn_readfirstlane(fl.w) != 0) return;
+                if (fed <= __builtin_amdgcn_readfirstlane(fl.y) + 7) break;
                 if ((++polls & 63u) == 0 && hopeless()) {
                     give_up();
                     return;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(4);
             }
+            Batch b0 = load_batch(fed);
+            __builtin_amdgcn_s_sleep(APART);
+            Batch b1 = load_batch(fed);
+            __builtin_amdgcn_s_sleep(APART);
+            Batch b2 = load_batch(fed);
+            Batch got;
+            for (;;) {
+                if (valid(b0)) {
+                    got = b0;
+                    break;
+                }
+                b0 = load_batch(fed);
+                if (valid(b1)) {
+                    got = b1;
+                    break;
+                }
+                b1 = load_batch(fed);
+                if (valid(b2)) {
+                    got = b2;
+                    break;
+                }
+                b2 = load_batch(fed);
+                if ((++polls & 15u) == 0) {
+                    if (__builtin_amdgcn_readfirstlane(flags_read4().w) != 0) return;
+                    if (hopeless()) {
+                        give_up();
+                        return;
+                    }
+                }
+            }
+#ifdef BMX_EXPERIMENTS
+            const bool tl = a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && fed == ED_BITS3_TL_GROUP - 1 && lane == 0;
+            if (tl) a.stamps[12] = __builtin_amdgcn_s_memrealtime();
+#endif
+            to_rings(got, fed);
+            ++fed;
+            flag_write(4, fed);
+#ifdef BMX_EXPERIMENTS
+            if (tl) a.stamps[13] = __builtin_amdgcn_s_memrealtime();
+            if (a.stamps != nullptr && blockIdx.x == a.stamp_block + 1 && fed == 2 && lane == 0)
+                a.stamps[16] = __builtin_amdgcn_s_memrealtime();
+#endif
         }
         return;
     }

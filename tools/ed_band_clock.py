@@ -24,4 +24,14 @@ for k, g in enumerate((1, 100, 300, 500)):
     gaps = np.diff(col)[ok[1:] & ok[:-1]]
     print(json.dumps({"group": g, "bands_that_have_it": int(ok.sum()), "us_behind_the_band_in_front_by_band": [round(float(v), 2) for v in gaps],
                       "mean_us": round(float(gaps.mean()), 2) if gaps.size else None}))
+ctx.set_knob("ed_stamp_block", 5)
+ctx.edit_distance_device(x, z)
+import ctypes as C
+out = (C.c_uint64 * (24 + 64 * 4))()
+ctx._L.bmx_exp_ed_stamps(ctx._h, out)
+t = [int(v) for v in out]
+p_g0_end, c_g0_end = t[24 + 4 * 5], t[24 + 4 * 6]
+print(json.dumps({"start_of_bands_5_and_6_us_after_band_5_finished_its_group_0": {
+    "band_5_finished_group_2": (t[10] - p_g0_end) / 100.0, "band_6_starts_group_0": (t[11] - p_g0_end) / 100.0,
+    "band_6_finished_group_0": (c_g0_end - p_g0_end) / 100.0}}))
 print(json.dumps({"ms": ctx.last_edit_distance_ms(), "distance": d}))
