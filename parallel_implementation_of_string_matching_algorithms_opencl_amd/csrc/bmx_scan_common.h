@@ -893,6 +893,73 @@ __device__ __forceinline__ void verify_stops(const ScanArgs &a, const LdsTables 
 }
 
 // lane_idx: 0 .. BLOCK-1.  [lo_t, hi_t): the tile's window starts to report (tile-local).
+// report_hit for a lane on its own: ONE LDS atomic (add 1, return) instead of ballot + leader's atomic + shuffle of the base -- the
+// quad-SAD walkers report inside a loop over a lane's stops, where the lanes of a wave rarely report together anyway.
+__device__ __forceinline__ void report_hit_lane(const ScanArgs &a, const LdsTables &tb, uint64_t astart, uint64_t tile_off)
+{
+    if (tb.sink != 0 || tb.stage_cap == 0) { // (wave-uniform) counting passes, kernels without a parking buffer
+        report_hit(a, tb, astart, tile_off);
+        return;
+    }
+    const uint32_t addr = (uint32_t)(uintptr_t)tb.stage_cnt;
+    uint32_t base;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(base) : "v"(addr), "v"(1u) : "memory");
+    base -= tb.stage_seen; // matches parked in this buffer before mine
+    if (base < tb.stage_cap) {
+        tb.stage[base] = astart | ((uint64_t)tb.pat_id << 56);
+        return;
+    }
+    if (a.dense_enabled != 0) return; // counted: the tile is dense (report_hit)
+    emit_hit(a, astart - a.first, astart + a.out_bias, false, tb.pat_id);
+}
+
+// The same for one QUARTER of a lane's positions, out of the lane's registers: the twenty sums again (five v_mqsad on the words
+// the filter loop still holds, no LDS request), the positions whose sum is 0 as a bit mask, and only those looked at.  verify_stops
+// went over the quarter with three LDS requests and their wait per four positions: ~2,000 cycles for the wave of a lane that
+// stops, which is nothing at one stop per MiB and a third of the run at one per 9 KiB (a 2-byte pattern on printable text: 0.96 ms
+// at 4 GiB against 0.61 for a pattern without matches).
+template <bool F8, int Q>
+__device__ __forceinline__ void verify_quarter(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t sbeg, const uint32_t (&d)[22],
+                                               uint32_t o, uint32_t &next_ok, uint32_t hi_t, uint64_t tile_off, uint32_t ref_a, uint32_t ref_b,
+                                               uint32_t k0)
+{
+    const uint32_t m = tb.m;
+    const u32x4 z = {0, 0, 0, 0};
+    uint32_t stops = 0;
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        const int k = 5 * Q + g;
+        u32x4 r;
+        if (F8) {
+            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d[k] | ((uint64_t)d[k + 1] << 32), ref_b, z);
+            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d[k + 1] | ((uint64_t)d[k + 2] << 32), ref_a, r);
+        } else {
+            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d[k] | ((uint64_t)d[k + 1] << 32), ref_a, z);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stops |= (r[j] == 0 ? 1u : 0u) << (4 * g + j);
+    }
+    while (stops != 0) {
+        const uint32_t t = (uint32_t)__ffs((int)stops) - 1u;
+        stops &= stops - 1u;
+        const uint32_t p = sbeg + 20u * Q + t - o; // window start (wraps to a huge value for stops before the tile's first window)
+        if (p >= hi_t || p < next_ok) continue;
+        const uint32_t i = p + m - 1; // kernel1.cl:15: index of the window's last character
+        // kernel1.cl:20-22.  A sum of 0 against a reference word without a zero byte IS the equality of the window's
+        // last F characters (all of them, for a pattern shorter than F): the comparison goes on from there
+        uint32_t k = k0;
+        while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+        if (k == m) { // kernel1.cl:24
+            report_hit_lane(a, tb, tile_off + (uint64_t)p, tile_off);
+            next_ok = p + 1;
+            continue;
+        }
+        const int b = (int)tb.bad[T[i]];
+        const int e1 = b - (int)k > 1 ? b - (int)k : 1;    // kernel1.cl:28
+        const int e2 = (int)tb.good[k];                     // kernel1.cl:29
+        next_ok = p + (uint32_t)(k == 0 ? e1 : (e1 > e2 ? e1 : e2)); // kernel1.cl:30-33
+    }
+}
 template <bool F8>
 __device__ __forceinline__ void walk_lane_sad(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lane_idx,
                                               uint32_t lo_t, uint32_t hi_t, uint64_t tile_off)
@@ -947,10 +1014,10 @@ __device__ __forceinline__ void walk_lane_sad(const ScanArgs &a, const LdsTables
                            : (no_zero_byte(ref_b, covered < 4 ? covered : 4) && (covered <= 4 || no_zero_byte(ref_a, covered - 4)));
     const uint32_t k0 = exact ? covered : 0u; // (wave-uniform)
     uint32_t next_ok = lo_t;
-    if (q0 == 0) verify_stops<F8>(a, tb, T, sbeg, sbeg + 20, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
-    if (q1 == 0) verify_stops<F8>(a, tb, T, sbeg + 20, sbeg + 40, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
-    if (q2 == 0) verify_stops<F8>(a, tb, T, sbeg + 40, sbeg + 60, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
-    if (q3 == 0) verify_stops<F8>(a, tb, T, sbeg + 60, sbeg + 80, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
+    if (q0 == 0) verify_quarter<F8, 0>(a, tb, T, sbeg, d, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
+    if (q1 == 0) verify_quarter<F8, 1>(a, tb, T, sbeg, d, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
+    if (q2 == 0) verify_quarter<F8, 2>(a, tb, T, sbeg, d, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
+    if (q3 == 0) verify_quarter<F8, 3>(a, tb, T, sbeg, d, o, next_ok, hi_t, tile_off, ref_a, ref_b, k0);
 }
 
 // wait until at most n of this wave's vector-memory operations are outstanding

@@ -352,10 +352,11 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
     // of 12: 0.20 / 0.22 / 0.28): there it only takes over from m = 8
     const bool uniform_like = sigma > 0 ? sigma > 64 : distinct > 4;
     if (is_short) {
-        // m = 3, 4 with rare matches: the quad-SAD skip loop (4 GiB printable text, steady protocol, ms: m = 3: 0.62 against
-        // 0.75 for the short-pattern kernel, m = 4: 0.61 against 0.72); m = 2 (one position in 9,000): its stops cost it
-        // more than the short-pattern kernel's any-match filter (1.30 against 1.15); m = 1 and dense results: 68 KiB tiles
-        if (*sparse && canonical && m >= 3 && sigma > 64 && fits(VARIANT_SAD)) {
+        // m = 2, 3, 4 with rare matches: the quad-SAD skip loop (4 GiB printable text, steady protocol, ms: m = 3: 0.61 against
+        // 0.75 for the short-pattern kernel, m = 4: 0.60 against 0.72; m = 2 -- one position in 9,000 stops it -- since its stops
+        // are verified out of registers and reported per lane: 0.70 against 0.77, before: 0.96); m = 1 and dense results: the
+        // short-pattern kernel
+        if (*sparse && canonical && m >= 2 && sigma > 64 && fits(VARIANT_SAD)) {
             *use_short_kernel = false;
             return VARIANT_SAD;
         }
