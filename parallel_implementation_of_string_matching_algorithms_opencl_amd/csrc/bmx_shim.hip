@@ -373,7 +373,11 @@ int pick_variant(const bmx_ctx *ctx, const char *pat, int32_t m, bool canonical,
         // with the parking ledger its matches cost it nothing in the loop: 4 GiB printable text, steady protocol, one match
         // per MiB, ms: m = 16: 0.620 against 0.645-0.660 byte-wise (bench.py: 0.622 against 0.651), m = 64: 0.620 against
         // 0.646, m = 4..12: 0.605-0.61 against 0.63-0.93 for the skip loop on 36 KiB tiles.  It needs the canonical tables.
-        if (canonical && (uniform_like || m >= 8) && fits(VARIANT_SAD)) return VARIANT_SAD;
+        // On English-LIKE text it took over from m = 8 only while a stop cost its wave ~2,000 cycles; with stops verified out of
+        // registers (verify_quarter) it wins from m = 5 on (1 GiB, ms, quad-SAD / skip loop on 36 KiB tiles: ` esh ` 0.40 / 0.52,
+        // a word of 6: 0.25 / 0.29, of 8: 0.18 / 0.23, two words of 16: 0.22 / 0.23): every pattern that is not "short".
+        (void)uniform_like;
+        if (canonical && fits(VARIANT_SAD)) return VARIANT_SAD;
         // short patterns: long walks, 32 waves per CU hide them better (4 GiB printable text, ms, byte-wise 76 KiB / skip loop
         // 36 KiB / the latter with a stolen tail: m = 8: - / 0.742 / 0.750, m = 10: 0.768 / 0.726 / 0.690, m = 12: 0.727 / 0.752 /
         // 0.697, m = 13: 0.703 / 0.775 / 0.714, m = 15: 0.685 / 0.766 / 0.715)

@@ -551,7 +551,7 @@ def test_walker_follows_the_texts_alphabet(built, port):
     with host.Context(0) as c:
         # (up to 64 distinct bytes in the sample: prose-like -- the quad-SAD skip loop from m = 8, the skip loop below, the
         # short-pattern kernel up to m = 4; more: spread like random text -- quad-SAD from m = 3)
-        for text, slots in ((english, {9: 87, 6: 2, 16: 87, 3: 29, 2: 29}), (dna, {9: 88, 12: 88, 7: 88, 6: 88, 5: 88, 16: 53, 40: 53, 4: 29, 3: 29, 2: 29, 1: 0}),
+        for text, slots in ((english, {9: 87, 6: 87, 16: 87, 3: 29, 2: 29}), (dna, {9: 88, 12: 88, 7: 88, 6: 88, 5: 88, 16: 53, 40: 53, 4: 29, 3: 29, 2: 29, 1: 0}),
                             (p95, {9: 87, 6: 87, 16: 87, 4: 87, 3: 87, 2: 87, 1: 29})):
             pats = {}
             for m in slots:
