@@ -38,7 +38,8 @@ static_assert(bmx::MAX_PATTERN == BMX_MAX_PATTERN, "header and kernel disagree")
 static_assert(bmx::MAX_MULTI == BMX_MAX_MULTI, "header and kernel disagree");
 
 // bmx_sort.hip
-int bmx_internal_radix_sort(uint64_t *d_keys, uint64_t n, hipStream_t stream, char *err, size_t errlen);
+int bmx_internal_radix_sort(uint64_t *d_keys, uint64_t n, unsigned end_bit, void **scratch, size_t *scratch_bytes, hipStream_t stream,
+                            char *err, size_t errlen);
 // bmx_sa.hip
 int bmx_internal_suffix_array(const uint8_t *d_text, uint32_t n, int32_t *d_sa, hipStream_t stream, float *ms_out,
                               int *rounds_out, void **ws, size_t *ws_bytes, uint32_t **pinned, int flags, char *err, size_t errlen);
@@ -209,6 +210,8 @@ struct bmx_ctx {
     bool last_short = false;               // ... was for a short pattern (short_pattern(): its fill pass tests every position, nothing is walked)
     bool last_counted = false;             // ... and its scan kernel left the per-tile / per-wave match counts the fill pass starts from
     bool last_fillable = false;
+    void *d_sort_scratch = nullptr;        // second key array + rocPRIM's temporary storage of the large sort (grown on demand, kept)
+    size_t sort_scratch_bytes = 0;
     uint32_t *d_bucket_cnt = nullptr;      // ORDER_BUCKETS, re-armed by order_kernel
     uint64_t *d_bucket_store = nullptr;    // ORDER_BUCKETS x ORDER_BUCKET_CAP
     uint32_t *d_overflow = nullptr;
@@ -525,6 +528,7 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
+    if (ctx->d_sort_scratch) (void)hipFree(ctx->d_sort_scratch);
     if (ctx->ed_ws) (void)hipFree(ctx->ed_ws);
     if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
     if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
@@ -841,7 +845,12 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(stream));
         } else {
-            int rc = bmx_internal_radix_sort(d_match_positions, stored, stream, g_err, sizeof g_err);
+            // (positions are below base offset + text length)
+            const uint64_t top = ctx->last_args.out_bias + ctx->last_args.own_end; // (aligned coordinate + bias = reported offset)
+            unsigned bits = 1;
+            while (bits < 64 && (top >> bits) != 0) ++bits;
+            int rc = bmx_internal_radix_sort(d_match_positions, stored, bits, &ctx->d_sort_scratch, &ctx->sort_scratch_bytes, stream, g_err,
+                                             sizeof g_err);
             if (rc != BMX_OK) return rc;
         }
     }

@@ -12,24 +12,39 @@
 
 #include "bmx.h"
 
-int bmx_internal_radix_sort(uint64_t *d_keys, uint64_t n, hipStream_t stream, char *err, size_t errlen)
+// end_bit: the keys are < 2^end_bit (a match position is below base offset + text length: 33 bits for 4 GiB, where all 64 cost
+// eight passes instead of five).  *scratch / *scratch_bytes: the caller's (the context's) buffer for the second key array and
+// rocPRIM's temporary storage, grown here when it is too small and kept: a hipMalloc / hipFree pair per call costs more than the
+// sort of a few hundred thousand keys (hipFree waits for the device).
+int bmx_internal_radix_sort(uint64_t *d_keys, uint64_t n, unsigned end_bit, void **scratch, size_t *scratch_bytes, hipStream_t stream,
+                            char *err, size_t errlen)
 {
     if (n < 2) return BMX_OK;
-    uint64_t *d_alt = nullptr;
-    void *d_tmp = nullptr;
+    if (end_bit < 1 || end_bit > 64) end_bit = 64;
     size_t tmp_bytes = 0;
-    hipError_t e = hipMalloc(&d_alt, n * sizeof(uint64_t));
+    const size_t alt_bytes = (n * sizeof(uint64_t) + 255) & ~(size_t)255;
+    hipError_t e;
+    {
+        rocprim::double_buffer<uint64_t> probe(d_keys, d_keys);
+        e = rocprim::radix_sort_keys(nullptr, tmp_bytes, probe, (size_t)n, 0, end_bit, stream);
+    }
+    if (e == hipSuccess && *scratch_bytes < alt_bytes + tmp_bytes) {
+        if (*scratch) (void)hipFree(*scratch);
+        *scratch = nullptr;
+        *scratch_bytes = 0;
+        const size_t want = (alt_bytes + tmp_bytes) + (alt_bytes + tmp_bytes) / 2; // (room for the next, somewhat longer list)
+        e = hipMalloc(scratch, want);
+        if (e == hipSuccess) *scratch_bytes = want;
+    }
     if (e == hipSuccess) {
+        uint64_t *d_alt = (uint64_t *)*scratch;
+        void *d_tmp = (char *)*scratch + alt_bytes;
         rocprim::double_buffer<uint64_t> keys(d_keys, d_alt);
-        e = rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, (size_t)n, 0, 64, stream);
-        if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
-        if (e == hipSuccess) e = rocprim::radix_sort_keys(d_tmp, tmp_bytes, keys, (size_t)n, 0, 64, stream);
+        e = rocprim::radix_sort_keys(tmp_bytes ? d_tmp : nullptr, tmp_bytes, keys, (size_t)n, 0, end_bit, stream);
         if (e == hipSuccess && keys.current() != d_keys)
             e = hipMemcpyAsync(d_keys, keys.current(), n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
     }
-    if (d_tmp) (void)hipFree(d_tmp);
-    if (d_alt) (void)hipFree(d_alt);
     if (e != hipSuccess) {
         if (err) snprintf(err, errlen, "radix sort of %llu matches: %s", (unsigned long long)n, hipGetErrorString(e));
         return BMX_ERR_HIP;
