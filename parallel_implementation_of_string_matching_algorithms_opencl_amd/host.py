@@ -219,11 +219,13 @@ class Context:
             self._h = C.c_void_p()
 
     def set_knob(self, name: str, value: int):
-        """libbmx_exp.so only (bmx_exp_set_knob): max_grid, no_dense, no_text_sample, multi_no_qgram, ed_lag, ed_group, sa_flags."""
+        """libbmx_exp.so only (bmx_exp_set_knob): max_grid, no_dense, no_text_sample, multi_no_qgram, ed_lag, ed_group, ed_step_x,
+        ed_stamp_block, sa_flags."""
         self._chk(self._L.bmx_exp_set_knob(self._h, name.encode(), int(value)), "bmx_exp_set_knob")
 
     def ed_stamps(self):
-        """libbmx_exp.so only (bmx_exp_ed_stamps): cycle counts of one band of the last edit distance (ed variants 11, 12)."""
+        """libbmx_exp.so only (bmx_exp_ed_stamps): cycle counts of one band of the last edit distance (ed variants 11, 12, 13), the
+        timeline of one hand-over and every band's clock at four of its groups (variant 13)."""
         out = (C.c_uint64 * (24 + 64 * 4))()
         self._chk(self._L.bmx_exp_ed_stamps(self._h, out), "bmx_exp_ed_stamps")
         keys = ["groups", "cycles_in_steps", "cycles_between", "cycles_loop", "cycles_validate", "steps_per_group", "rows_per_step", "band_steps"]
