@@ -271,6 +271,20 @@ def test_misaligned_device_pointers(ctx, port):
     assert np.array_equal(pos.cpu().numpy().astype(np.uint64), want)
 
 
+def test_mid_size_lists_take_the_large_sort_with_few_key_bits(ctx, port):
+    """More matches than the position buckets order (65,536) but no dense tiles: the list is ordered by the radix sort over the
+    key bits positions can have (base offset + length), its scratch kept by the context -- a list, a longer one (the scratch
+    grows), a short one again, with a base offset beyond 2^40 and without."""
+    rng = np.random.default_rng(71)
+    for mib, base in ((96, 0), (160, (1 << 40) + 12345), (80, 7)):
+        text = (rng.integers(0, 4, mib << 20).astype(np.uint8) * 2 + 65)  # four symbols
+        pat = bytes(text[1000:1005])
+        want = port.search(text, pat) + np.uint64(base)
+        assert want.size > 65_536
+        got = dev_search(ctx, text, pat, base_offset=base) if base else dev_search(ctx, text, pat)
+        assert np.array_equal(got, want), (mib, base, got.size, want.size)
+
+
 def test_dense_hits_take_the_radix_sort_path(ctx, port):
     """'aaaa...' / 'aa': ~n matches, far beyond the in-LDS sort (8192)."""
     n = 1_000_000
