@@ -175,6 +175,25 @@ struct LdsTables {
 // reservation per workgroup and tile matters: every append increments the same counter and the chip
 // retires ~80 M same-address atomics per second, so per wave and tile (first version) 246 k flushes for
 // the 12.6 M matches above still took 3.0 ms.  What does not fit in the buffer goes the direct way.
+// kernel1.cl:20-22 behind a filter that has already matched k characters: how many characters match from the window's end
+// (index i) on.  Eight characters per LDS round trip -- the sixteen byte requests leave together -- where the plain loop pays a
+// round trip per character: a true match of a 64-byte pattern cost its lane's WAVE ~4,500 cycles of dependent reads, and the
+// workgroup waits for that wave at the tile barrier (configs 3 and 3b with their 4,161 planted matches: 0.019 / 0.023 ms of the
+// kernel's 0.626).  Not for the byte-wise walker, whose loop mostly ends at its first comparison.
+__device__ __forceinline__ uint32_t match_back(const LdsTables &tb, const uint8_t *T, uint32_t i, uint32_t k)
+{
+    const uint32_t m = tb.m;
+    while (k + 8 <= m) {
+        uint32_t diff = 0; // bit j: character k + j differs
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) diff |= (uint32_t)(T[i - k - j] != tb.pat[m - 1 - k - j]) << j;
+        if (diff != 0) return k + (uint32_t)__ffs((int)diff) - 1u;
+        k += 8;
+    }
+    while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+    return k;
+}
+
 __device__ __forceinline__ void report_hit(const ScanArgs &a, const LdsTables &tb, uint64_t astart, uint64_t tile_off)
 {
     if (tb.sink == 1) { // wave-uniform
@@ -317,7 +336,7 @@ __device__ __forceinline__ void walk_lane(const ScanArgs &a, const LdsTables &tb
                     }
                 }
                 if (!have_k) {
-                    while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+                    k = match_back(tb, T, i, k);
                     if (k == m) {
                         const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
                         report_hit(a, tb, astart, tile_off);
@@ -368,8 +387,7 @@ __device__ __forceinline__ void walk_lane_qgram(const ScanArgs &a, const LdsTabl
             i += s;
             continue;
         }
-        uint32_t k = 0; // kernel1.cl:20-22
-        while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+        const uint32_t k = match_back(tb, T, i, 0); // kernel1.cl:20-22
         if (k == m) { // kernel1.cl:24
             const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
             report_hit(a, tb, astart, tile_off);
@@ -424,8 +442,7 @@ __device__ __forceinline__ void walk_lane_qgram8(const ScanArgs &a, const LdsTab
             const uint32_t x0 = w0 ^ tb.sad_b;
             k = x0 != 0 ? 4u + ((uint32_t)__clz((int)x0) >> 3) : 8u;
         }
-        if (k == 8)
-            while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+        if (k == 8) k = match_back(tb, T, i, 8);
         if (k == m) { // kernel1.cl:24
             const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
             report_hit(a, tb, astart, tile_off);
@@ -850,49 +867,6 @@ __device__ __forceinline__ void fill_tile_short(const ScanArgs &a, const LdsTabl
 
 constexpr uint32_t SAD_SEG = 80; // filter positions (bytes) per lane: 16 x odd
 
-// The stops among the filter positions [s_lo, s_hi) of a lane (a multiple of 4 apart, 16-byte aligned start).  next_ok: the
-// first window start the reference's loop could visit next (carried from one piece of the lane's positions to the next).
-template <bool F8>
-__device__ __forceinline__ void verify_stops(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t s_lo, uint32_t s_hi,
-                                             uint32_t o, uint32_t &next_ok, uint32_t hi_t, uint64_t tile_off, uint32_t ref_a,
-                                             uint32_t ref_b, uint32_t k0)
-{
-    const uint32_t m = tb.m;
-    for (uint32_t s = s_lo; s < s_hi; s += 4) {
-        lds_c32 *q = (lds_c32 *)to_lds(T + s);
-        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-        const u32x4 z = {0, 0, 0, 0};
-        u32x4 r;
-        if (F8) {
-            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d0 | ((uint64_t)d1 << 32), ref_b, z);
-            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d1 | ((uint64_t)d2 << 32), ref_a, r);
-        } else {
-            r = __builtin_amdgcn_mqsad_u32_u8((uint64_t)d0 | ((uint64_t)d1 << 32), ref_a, z);
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            if (r[j] != 0) continue;
-            const uint32_t p = s + j - o; // window start (wraps to a huge value for stops before the tile's first window)
-            if (p >= hi_t || p < next_ok) continue;
-            const uint32_t i = p + m - 1; // kernel1.cl:15: index of the window's last character
-            // kernel1.cl:20-22.  A sum of 0 against a reference word without a zero byte IS the equality of the window's
-            // last F characters (all of them, for a pattern shorter than F): the comparison goes on from there
-            uint32_t k = k0;
-            while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
-            if (k == m) { // kernel1.cl:24
-                report_hit(a, tb, tile_off + (uint64_t)p, tile_off);
-                next_ok = p + 1;
-                continue;
-            }
-            const int b = (int)tb.bad[T[i]];
-            const int e1 = b - (int)k > 1 ? b - (int)k : 1;    // kernel1.cl:28
-            const int e2 = (int)tb.good[k];                     // kernel1.cl:29
-            next_ok = p + (uint32_t)(k == 0 ? e1 : (e1 > e2 ? e1 : e2)); // kernel1.cl:30-33
-        }
-    }
-}
-
-// lane_idx: 0 .. BLOCK-1.  [lo_t, hi_t): the tile's window starts to report (tile-local).
 // report_hit for a lane on its own: ONE LDS atomic (add 1, return) instead of ballot + leader's atomic + shuffle of the base -- the
 // quad-SAD walkers report inside a loop over a lane's stops, where the lanes of a wave rarely report together anyway.
 __device__ __forceinline__ void report_hit_lane(const ScanArgs &a, const LdsTables &tb, uint64_t astart, uint64_t tile_off)
@@ -913,11 +887,12 @@ __device__ __forceinline__ void report_hit_lane(const ScanArgs &a, const LdsTabl
     emit_hit(a, astart - a.first, astart + a.out_bias, false, tb.pat_id);
 }
 
-// The same for one QUARTER of a lane's positions, out of the lane's registers: the twenty sums again (five v_mqsad on the words
-// the filter loop still holds, no LDS request), the positions whose sum is 0 as a bit mask, and only those looked at.  verify_stops
-// went over the quarter with three LDS requests and their wait per four positions: ~2,000 cycles for the wave of a lane that
+// The stops in one QUARTER of a lane's filter positions, out of the lane's registers: the twenty sums again (five v_mqsad on the
+// words the filter loop still holds, no LDS request), the positions whose sum is 0 as a bit mask, and only those looked at.
+// next_ok: the first window start the reference's loop could visit next (carried from one quarter to the next).  (The first
+// version went over the quarter with three LDS requests and their wait per four positions: ~2,000 cycles for the wave of a lane that
 // stops, which is nothing at one stop per MiB and a third of the run at one per 9 KiB (a 2-byte pattern on printable text: 0.96 ms
-// at 4 GiB against 0.61 for a pattern without matches).
+// at 4 GiB against 0.61 for a pattern without matches.)
 template <bool F8, int Q>
 __device__ __forceinline__ void verify_quarter(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t sbeg, const uint32_t (&d)[22],
                                                uint32_t o, uint32_t &next_ok, uint32_t hi_t, uint64_t tile_off, uint32_t ref_a, uint32_t ref_b,
@@ -947,8 +922,7 @@ __device__ __forceinline__ void verify_quarter(const ScanArgs &a, const LdsTable
         const uint32_t i = p + m - 1; // kernel1.cl:15: index of the window's last character
         // kernel1.cl:20-22.  A sum of 0 against a reference word without a zero byte IS the equality of the window's
         // last F characters (all of them, for a pattern shorter than F): the comparison goes on from there
-        uint32_t k = k0;
-        while (k < m && T[i - k] == tb.pat[m - 1 - k]) ++k;
+        const uint32_t k = k0 >= m ? m : match_back(tb, T, i, k0); // (wave-uniform: a pattern the filter covers whole is matched)
         if (k == m) { // kernel1.cl:24
             report_hit_lane(a, tb, tile_off + (uint64_t)p, tile_off);
             next_ok = p + 1;
