@@ -371,6 +371,7 @@ __device__ __forceinline__ uint32_t qgram_hash(uint32_t b0, uint32_t b1, uint32_
     return (w * 0x9E3779B1u) >> 20; // 12 bits
 }
 
+__device__ __forceinline__ void report_hit_lane(const ScanArgs &a, const LdsTables &tb, uint64_t astart, uint64_t tile_off);
 __device__ __forceinline__ void walk_lane_qgram(const ScanArgs &a, const LdsTables &tb, const uint8_t *T, uint32_t lo,
                                                 uint32_t hi, uint64_t tile_off)
 {
@@ -390,7 +391,7 @@ __device__ __forceinline__ void walk_lane_qgram(const ScanArgs &a, const LdsTabl
         const uint32_t k = match_back(tb, T, i, 0); // kernel1.cl:20-22
         if (k == m) { // kernel1.cl:24
             const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-            report_hit(a, tb, astart, tile_off);
+            report_hit_lane(a, tb, astart, tile_off);
             i += 1;
             continue;
         }
@@ -445,7 +446,7 @@ __device__ __forceinline__ void walk_lane_qgram8(const ScanArgs &a, const LdsTab
         if (k == 8) k = match_back(tb, T, i, 8);
         if (k == m) { // kernel1.cl:24
             const uint64_t astart = tile_off + (uint64_t)(i - (m - 1));
-            report_hit(a, tb, astart, tile_off);
+            report_hit_lane(a, tb, astart, tile_off);
             i += 1;
             continue;
         }
