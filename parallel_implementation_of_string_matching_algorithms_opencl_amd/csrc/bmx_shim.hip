@@ -97,6 +97,7 @@ struct Variant {
     void (*fill_count)(const bmx::ScanArgs); // the fill pass's first launch (tile counts)
     void (*fill_count_short)(const bmx::ScanArgs);
     bool steal = false; // the main kernel hands its last tiles out by ticket (scan_kernel MODE 12): the ordering kernel checks the tile count
+    bool steal_short = false; // ... the short-pattern kernel does
 };
 
 // The slot numbers are stable (tools/ and the notes in DESIGN.md refer to them), but the PRODUCT library
@@ -124,6 +125,11 @@ struct Variant {
     {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 7 || (W) == 8 ? 1 : ((W) == 3 ? 4 : ((W) == 10 ? 8 : 0)), bmx::scan_kernel<B, S, AUX, 12, W>, \
      bmx::scan_kernel<B, S, AUX, 0, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>, \
      bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>, true}
+// ... and the short-pattern kernel with a stolen tail as well
+#define BMX_TILE_SS(B, S, AUX, W) \
+    {0, B, S, 2, 0, 0, false, (W) == 3 || (W) == 10, (W) == 7 || (W) == 8 ? 1 : ((W) == 3 ? 4 : ((W) == 10 ? 8 : 0)), bmx::scan_kernel<B, S, AUX, 12, W>, \
+     bmx::scan_kernel<B, S, AUX, 12, 6>, bmx::scan_kernel<B, S, AUX, 9, 0>, bmx::scan_kernel<B, S, AUX, 9, 6>, \
+     bmx::scan_kernel<B, S, AUX, 10, 0>, bmx::scan_kernel<B, S, AUX, 10, 6>, true, true}
 // a product geometry with clock stamps (MODE 5: per tile phase, MODE 8: two stamps around the loop): everything the
 // product kernel does, the per-tile counts of short patterns included
 #define BMX_TILE_FM(B, S, AUX, MODE, W) \
@@ -139,7 +145,7 @@ struct Variant {
     {2, B, S, 3, 0, 0, (MODE) == 5, (W) == 10, (W) == 10 ? 8 : 0, bmx::scan_ring_kernel<B, S, AUX, W, MODE, P>, bmx::scan_ring_kernel<B, S, AUX, 0, MODE, P>, nullptr, nullptr, nullptr, nullptr}
 #define BMX_WAVE(WV, S, AUX, MODE, D, NB)                                                      \
     {1, (WV) * 64, S, NB, 0, 0, false, false, 0, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, bmx::scan_wave_kernel<WV, S, AUX, MODE, D, NB>, nullptr, nullptr, nullptr, nullptr}
-constexpr int N_VARIANTS = 89; // slots of the kernel table (built into this library or not)
+constexpr int N_VARIANTS = 90; // slots of the kernel table (built into this library or not)
 struct VariantTable {
     Variant v[N_VARIANTS];
     VariantTable()
@@ -726,7 +732,7 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(v.block), lds, stream, a);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
-        if (v.steal && !is_short) expect_tiles = (uint32_t)(a.tile_end - a.tile_begin);
+        if (is_short ? v.steal_short : v.steal) expect_tiles = (uint32_t)(a.tile_end - a.tile_begin);
         ctx->n_timed++;
         ctx->timed = true;
         ctx->last_args = a;
