@@ -8,6 +8,7 @@
 #include "bmx.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -728,10 +729,10 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
             HIPCHK(hipMemsetAsync(ctx->d_stamps, 0, words * sizeof(unsigned long long), stream));
             a.stamps = ctx->d_stamps;
         }
-        HIPCHK(hipEventRecord(ctx->ev0[slot], stream));
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(v.block), lds, stream, a);
+        // (the two timing events ride on the kernel's own dispatch packet -- hipExtLaunchKernel -- instead of a barrier packet in
+        // front of it and one behind: the command processor spent ~12 us per search on those)
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(v.block), lds, stream, ctx->ev0[slot], ctx->ev1[slot], 0, a);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(ctx->ev1[slot], stream));
         if (is_short ? v.steal_short : v.steal) expect_tiles = (uint32_t)(a.tile_end - a.tile_begin);
         ctx->n_timed++;
         ctx->timed = true;
