@@ -27,7 +27,7 @@ corpus -- at N = 8 this is configs[3] (32 GiB).
 
 Rank 0 prints ONE JSON line (contract in the task description) with two extra
 objects: `roofline` (scan kernel vs the HBM read roofline, duration from HIP
-events recorded around that kernel on its launch stream) and, at N = 1,
+events on that kernel's own dispatch, on its launch stream) and, at N = 1,
 `cpu_baseline` (the reference's serial CPU Boyer-Moore -- oracle/_ref when it
 is present, else the C restatement -- timed on this host over the same text,
 which doubles as the full-size bit-exactness check of the GPU match list).
@@ -35,7 +35,12 @@ Before the --warmup steps the device's clocks are ramped up with 40 untimed
 searches (--ramp-up; the first ~10 launches after the set-up's idle time run
 5-10 % slower); the line reports it as config.ramp_up_searches.
 The timed region keeps the scan kernels of consecutive searches apart, so that a
-launch's duration is the kernel's; what the same stream of searches reaches when
+launch's duration is the kernel's: at N = 1 the searches in flight (two contexts)
+are enqueued on ONE stream and each context's ordering kernel runs on a stream of
+its own (--scan-stream shared, bmx_set_order_overlap: the next scan starts right
+behind the one before, config.scan_stream says so); with an exchange (N > 1) every
+search in flight has its stream and the next scan waits for an event of the one
+before.  What the same stream of searches reaches when
 they may share the GPU is measured behind it with --measure-overlap and reported as
 config.whole_job_GBps_if_scans_may_overlap (never `value`; --overlap-scans times
 the whole region that way).
@@ -75,6 +80,11 @@ def parse_args(argv=None):
     ap.add_argument("--measure-overlap", action="store_true",
                     help="behind the timed region, time the same searches once more with overlapping scans and report it as "
                          "config.whole_job_GBps_if_scans_may_overlap (off by default: its launches would be in every profile of this command)")
+    ap.add_argument("--scan-stream", choices=["shared", "per-search"], default="shared",
+                    help="shared (default at N = 1): the searches in flight are enqueued on ONE stream and every context's ordering "
+                         "kernel runs on a stream of its own (bmx_set_order_overlap), so the scans follow each other directly; "
+                         "per-search: a stream per search in flight, the next scan behind an event of the one before (rounds 1-2, "
+                         "and always with an exchange: N > 1, --force-exchange)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="searches in flight (each with its own context and output buffer); 1 = strictly one at a time")
     ap.add_argument("--force-exchange", action="store_true",
@@ -375,6 +385,9 @@ def main():
     tables = host.build_tables(pat)  # host tables once, like BoyreMoore.cpp:150-190 (outside its timer too)
     lanes = []
     n_lanes = max(1, args.in_flight)
+    # one stream for every search in flight (their scans then follow each other directly, each context's ordering kernel on a
+    # stream of its own): not with an exchange behind the scan, whose collectives are stream-ordered behind the ordering kernel
+    shared_stream = args.scan_stream == "shared" and not multi and n_lanes > 1 and not args.overlap_scans and not args.measure_overlap
     d_text = None
     for li in range(n_lanes):
         c = make_context(args, local_rank)
@@ -383,7 +396,12 @@ def main():
         if d_text is None:
             d_text = spec.device_text(c, start, length, device=dev)
             torch.cuda.synchronize()  # the lanes' streams start behind the text
-        stream = torch.cuda.Stream(dev) if n_lanes > 1 else torch.cuda.current_stream(dev)
+        if shared_stream and lanes:
+            stream = lanes[0]["stream"]
+        else:
+            stream = torch.cuda.Stream(dev) if n_lanes > 1 else torch.cuda.current_stream(dev)
+        if shared_stream:
+            c.set_order_overlap(True)
         with torch.cuda.stream(stream):
             if multi:
                 x = shard.SlotExchange(c, world, rank, dev, slot=SLOT, via_host=rehearse)  # [count | offsets...] over RCCL
@@ -412,7 +430,7 @@ def main():
         collect(lane)  # the search this lane started len(lanes) steps ago
         with torch.cuda.stream(lane["stream"]):
             prev = last["lane"]
-            if prev is not None and prev is not lane and not args.overlap_scans:
+            if prev is not None and prev is not lane and not args.overlap_scans and not shared_stream:
                 prev["ctx"].stream_wait_last_scan(lane["stream"])  # two scans never overlap
             if multi:
                 lane["xchg"].start(lane["query"])  # scan, then order + all-gather + merge under the NEXT lane's scan
@@ -514,7 +532,7 @@ def main():
                   ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "single process"),
         "config": {"workload": spec.name, "text_bytes_total": spec.n, "text_bytes_per_gpu": n_own,
                    "pattern_bytes": m, "alphabet": "printable-95" if spec.kind == 0 else "ACGT",
-                   "matches": int(result.size), "library": args.library or "libbmx.so", "searches_in_flight": len(lanes), "scans_overlap": bool(args.overlap_scans), "ramp_up_searches": n_ramp,
+                   "matches": int(result.size), "library": args.library or "libbmx.so", "searches_in_flight": len(lanes), "scan_stream": ("one stream, the ordering kernels on their contexts' own (bmx_set_order_overlap)" if shared_stream else "one per search in flight, the next scan behind an event of the one before"), "scans_overlap": bool(args.overlap_scans), "ramp_up_searches": n_ramp,
                    "kernel_ms_first_launches": first_ms,
                    "whole_job_GBps_if_scans_may_overlap": None if overlap_value is None else round(overlap_value, 1), "sharding": f"{world} contiguous shard(s) + {m - 1} B halo",
                    "exchange": ("REHEARSAL on one GPU, gloo via host" if rehearse else

@@ -173,6 +173,14 @@ int bmx_search_device(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_o
  * the text it has just scanned and _finish remembers the number of distinct byte values per (d_text, n) pair (the 16
  * most recent).  The FIRST search on a text therefore goes by the pattern's own symbols and later ones by the text's:
  * _enqueue never waits for the device.  The match list does not depend on any of it. */
+/* Repeated searches through several contexts on ONE stream (search i of context A, search i + 1 of context B, ...): with on != 0
+ * a context's ordering kernel runs on a stream of the context's own behind its scan's stop event, so that `stream` holds nothing
+ * but scans and the next context's scan starts right behind this one (it used to start behind this one's ordering kernel: ~13 us
+ * per search on config 2); one CU is left out of the scan's grid for the ordering kernels (the scan is HBM-bound).  _finish is
+ * where the list is valid, as before; work enqueued on `stream` after _enqueue is ordered behind the SCAN only; a second _enqueue
+ * on the same context without _finish waits for the first one's ordering kernel.  Off (the state of a new context): scan and
+ * ordering on `stream`.  Inside a graph capture the ordering stays on `stream` either way. */
+int bmx_set_order_overlap(bmx_ctx *ctx, int on);
 int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint64_t n_own,
                               uint64_t base_offset, const char *pat, int32_t m,
                               const int32_t *good, const int32_t *bad,

@@ -229,6 +229,10 @@ struct bmx_ctx {
     unsigned long long *d_stamps = nullptr; // diagnostic builds only (bmx_scan_stamps)
     uint64_t stamp_words = 0;
     bool armed = false;                    // counters known to be zero
+    int order_overlap = 0;                 // bmx_set_order_overlap
+    hipStream_t order_stream = nullptr;    // ... the context's own stream for the ordering kernel
+    hipEvent_t ev_order = nullptr;         // ... recorded behind it
+    bool order_forked = false;             // the last enqueue's ordering kernel went there and _finish has not been called yet
     bool last_sorted = false;              // the last finish had to sort (the order kernel could not order the list)
     static constexpr int EV_RING = 64;     // event pairs around the last EV_RING scan kernels
     hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
@@ -536,6 +540,8 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_stamps) (void)hipFree(ctx->d_stamps);
     if (ctx->d_sort_scratch) (void)hipFree(ctx->d_sort_scratch);
+    if (ctx->ev_order) (void)hipEventDestroy(ctx->ev_order);
+    if (ctx->order_stream) (void)hipStreamDestroy(ctx->order_stream);
     if (ctx->ed_ws) (void)hipFree(ctx->ed_ws);
     if (ctx->sa_ws) (void)hipFree(ctx->sa_ws);
     if (ctx->sa_pinned) (void)hipHostFree(ctx->sa_pinned);
@@ -545,6 +551,13 @@ void bmx_ctx_destroy(bmx_ctx *ctx)
         if (ctx->ev1[i]) (void)hipEventDestroy(ctx->ev1[i]);
     }
     delete ctx;
+}
+
+int bmx_set_order_overlap(bmx_ctx *ctx, int on)
+{
+    if (!ctx) return BMX_ERR_ARG;
+    ctx->order_overlap = on != 0;
+    return BMX_OK;
 }
 
 int bmx_set_variant(bmx_ctx *ctx, int variant, int blocks_per_cu)
@@ -624,6 +637,10 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     hipStream_t stream = (hipStream_t)stream_v;
     HIPCHK(hipSetDevice(ctx->device));
     ctx->timed = false;
+    if (ctx->order_forked) { // (a second search on this context without _finish in between: behind the first one's ordering kernel)
+        HIPCHK(hipStreamWaitEvent(stream, ctx->ev_order, 0));
+        ctx->order_forked = false;
+    }
     if (!ctx->armed) { // first use, or a previous enqueue failed half way: zero the device counters
         HIPCHK(hipMemsetAsync(ctx->d_count, 0, sizeof(unsigned long long), stream));
         HIPCHK(hipMemsetAsync(ctx->d_bucket_cnt, 0, bmx::ORDER_BUCKETS * sizeof(uint32_t), stream));
@@ -692,7 +709,8 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
         }
         uint64_t nblocks = a.tile_end - a.tile_begin; // kind 0: one tile per workgroup at a time
         if (v.kind == 1) nblocks = (nblocks + v.block / 64 - 1) / (v.block / 64); // one piece per wave
-        const uint64_t max_grid = (uint64_t)blocks_per_cu_for(ctx, v, m) * ctx->num_cu;
+        // (order overlap: one CU stays free for the ordering kernel of the search before -- the scan is HBM-bound, 255 CUs read as fast)
+        const uint64_t max_grid = (uint64_t)blocks_per_cu_for(ctx, v, m) * (ctx->num_cu - (ctx->order_overlap && ctx->num_cu > 8 ? 1 : 0));
         uint32_t grid = (uint32_t)std::min<uint64_t>(nblocks, max_grid);
         if (ctx->max_grid > 0) grid = std::min<uint32_t>(grid, (uint32_t)ctx->max_grid); // (libbmx_exp.so only)
 
@@ -746,12 +764,30 @@ int bmx_search_device_enqueue(bmx_ctx *ctx, const void *d_text, uint64_t n, uint
     }
 
     // ascending list from the position buckets, {count, needs_sort} for the host, counters re-armed
-    hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, stream, out, capacity, ctx->d_count,
+    // bmx_set_order_overlap: the ordering kernel runs on a stream of the context's own behind the scan's stop event, so that the
+    // caller's stream holds nothing but scans -- the next search's scan (another context, same stream) starts right behind this
+    // one instead of behind this one's ordering kernel.  Not inside a graph capture (the fork would become part of the graph).
+    hipStream_t order_stream = stream;
+    bool forked = false;
+    if (ctx->order_overlap && ctx->timed) { // (timed: a scan was launched just now, its stop event is the one to wait for)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        if (cap == hipStreamCaptureStatusNone) {
+            if (!ctx->order_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->order_stream, hipStreamNonBlocking));
+            if (!ctx->ev_order) HIPCHK(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+            HIPCHK(hipStreamWaitEvent(ctx->order_stream, ctx->ev1[(ctx->n_timed - 1) % bmx_ctx::EV_RING], 0));
+            order_stream = ctx->order_stream;
+            forked = true;
+        }
+    }
+    hipLaunchKernelGGL(bmx::order_kernel, dim3(1), dim3(bmx::ORDER_THREADS), 0, order_stream, out, capacity, ctx->d_count,
                        ctx->d_bucket_cnt, ctx->d_bucket_store, ctx->d_overflow, ctx->d_status, ctx->h_status_dev,
                        ++ctx->seq, (uint64_t *)nullptr, 1u, ctx->text_sample ? (const uint8_t *)d_text : nullptr, n,
                        expect_tiles);
     ctx->last_text = d_text, ctx->last_text_n = n;
     HIPCHK(hipGetLastError());
+    if (forked) HIPCHK(hipEventRecord(ctx->ev_order, ctx->order_stream));
+    ctx->order_forked = forked;
     ctx->armed = true;
     return BMX_OK;
 }
@@ -771,7 +807,7 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
         uint64_t spins = 0;
         while (__atomic_load_n(&ctx->h_status[2], __ATOMIC_ACQUIRE) != want) {
             if ((++spins & 0xFFFF) == 0) {
-                hipError_t q = hipStreamQuery(stream);
+                hipError_t q = hipStreamQuery(ctx->order_forked ? ctx->order_stream : stream);
                 if (q != hipSuccess && q != hipErrorNotReady) {
                     set_err("scan failed: %s", hipGetErrorString(q));
                     ctx->armed = false;
@@ -785,6 +821,7 @@ int bmx_search_device_finish(bmx_ctx *ctx, uint64_t *d_match_positions, uint64_t
             __builtin_ia32_pause();
         }
     }
+    ctx->order_forked = false; // (the ordering kernel is done: whatever follows on `stream` sees its list)
     const uint64_t total = ctx->h_status[0];
     const bool needs_sort = ctx->h_status[1] == 1;
     remember_sigma(ctx, ctx->last_text, ctx->last_text_n, (int)ctx->h_status[6]);

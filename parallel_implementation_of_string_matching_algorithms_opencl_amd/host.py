@@ -89,6 +89,7 @@ SYMBOLS = [
     ("bmx_scan_geometry", C.c_int, [C.c_void_p, C.c_int32, _u64p]),
     ("bmx_set_variant", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("bmx_variant_count", C.c_int, []),
+    ("bmx_set_order_overlap", C.c_int, [C.c_void_p, C.c_int]),
     ("bmx_last_variant", C.c_int, [C.c_void_p]),
     ("bmx_edit_distance", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p]),
     ("bmx_edit_distance_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, _u64p,
@@ -217,6 +218,11 @@ class Context:
         if self._h:
             self._L.bmx_ctx_destroy(self._h)
             self._h = C.c_void_p()
+
+    def set_order_overlap(self, on: bool = True):
+        """bmx_set_order_overlap: this context's ordering kernel on a stream of its own behind the scan (searches of several
+        contexts enqueued on one stream then scan back to back)."""
+        self._chk(self._L.bmx_set_order_overlap(self._h, 1 if on else 0), "bmx_set_order_overlap")
 
     def set_knob(self, name: str, value: int):
         """libbmx_exp.so only (bmx_exp_set_knob): max_grid, no_dense, no_text_sample, multi_no_qgram, ed_lag, ed_group, ed_step_x,

@@ -271,6 +271,53 @@ def test_misaligned_device_pointers(ctx, port):
     assert np.array_equal(pos.cpu().numpy().astype(np.uint64), want)
 
 
+def test_order_overlap_two_contexts_on_one_stream(port):
+    """bmx_set_order_overlap: two contexts take turns on ONE stream, each one's ordering kernel on a stream of its own behind its
+    scan -- sparse lists, a list that takes the large sort, a dense one (fill pass), an empty text; every list == the oracle's."""
+    import torch
+
+    from parallel_implementation_of_string_matching_algorithms_opencl_amd import host
+
+    rng = np.random.default_rng(83)
+    texts = [(rng.integers(0, 95, 8 << 20) + 32).astype(np.uint8), (rng.integers(0, 4, 96 << 20).astype(np.uint8) * 2 + 65),
+             np.full(1 << 20, ord("a"), dtype=np.uint8)]
+    jobs = []
+    for t in texts[:1]:
+        for m in (2, 5, 16):
+            jobs.append((t, bytes(t[4000:4000 + m])))
+    jobs.append((texts[1], bytes(texts[1][1000:1005])))  # ~98 k matches: large sort
+    jobs.append((texts[2], b"aa"))                       # dense: fill pass
+    jobs = jobs * 2
+    ctxs = [host.Context(0), host.Context(0)]
+    for c in ctxs:
+        c.set_order_overlap(True)
+    stream = torch.cuda.Stream()
+    d_texts = {id(t): torch.from_numpy(t).cuda() for t in texts}
+    outs = [torch.empty(1 << 21, dtype=torch.int64, device="cuda") for _ in ctxs]
+    torch.cuda.synchronize()
+    pending = [None, None]
+
+    def collect(k):
+        if pending[k] is not None:
+            tt, pp, q = pending[k]
+            total = q.finish()
+            got = outs[k][:total].cpu().numpy().astype(np.uint64)
+            assert np.array_equal(got, port.search(tt, pp)), pp
+            pending[k] = None
+
+    with torch.cuda.stream(stream):
+        for i, (t, pat) in enumerate(jobs):
+            k = i % 2
+            collect(k)
+            q = ctxs[k].prepare(d_texts[id(t)], pat, outs[k])
+            q.enqueue()
+            pending[k] = (t, pat, q)
+        collect(0)
+        collect(1)
+    for c in ctxs:
+        c.close()
+
+
 def test_mid_size_lists_take_the_large_sort_with_few_key_bits(ctx, port):
     """More matches than the position buckets order (65,536) but no dense tiles: the list is ordered by the radix sort over the
     key bits positions can have (base offset + length), its scratch kept by the context -- a list, a longer one (the scratch
