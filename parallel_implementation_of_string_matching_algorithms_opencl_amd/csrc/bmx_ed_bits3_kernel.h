@@ -29,7 +29,7 @@
 // fed).  LDS instructions of a wave complete in order, so "data, then counter" needs no wait on the writer's side.  Batches end
 // where the groups of the band in front end (entries up to k G with its group k + 1): a batch is complete with ONE group.
 // What goes to HBM is what went there before ({F, tag} per row): the value bands, the meet kernel and the cut rows do not change.
-// Measured (64k x 64k, profiles/r03_ed_*): 2.20 ms (bits2) -> 1.49 ms; per step 172 cycles, ~300 between groups, lag 180 steps.
+// Measured (64k x 64k, profiles/r03_ed_*): 2.20 ms (bits2) -> 1.47 ms; per step 172 cycles, ~300 between groups, lag 155 steps.
 //
 // Reference: EditDistance-1/EditDistance-1/kernal.cl:5-56 + EditDistance-1.cpp:278-345; recurrence as sequential.c:18-46.
 #pragma once
